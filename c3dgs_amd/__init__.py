@@ -1,0 +1,35 @@
+"""c3dgs_amd -- MI355X (gfx950) rasterizer + VQ hot path of Compressed 3D Gaussian Splatting.
+
+Drop-in for the reference's two native extensions and the Python directly around them:
+
+    c3dgs_amd.rasterizer  <->  diff_gaussian_rasterization_no_camera (and its two sibling packages)
+    c3dgs_amd.vq          <->  weighted_distance._C.weightedDistance + compression/vq.py
+
+The numeric work runs in c3dgs_amd/libc3dgs_hip.so (include/c3dgs_hip.h); build it with
+`python -m c3dgs_amd.build`.  There is no CPU fallback.
+"""
+import sys
+import types
+
+from . import rasterizer, vq  # noqa: F401
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, GaussianRasterizerIndexed,  # noqa: F401
+                         getProjectionMatrix, mat_to_quat, quat_to_mat, rasterize_gaussians,
+                         rasterize_gaussians_indexed, rasterize_gaussians_indexed_camera)
+from .vq import (CompressionSettings, VectorQuantize, compress_color, compress_covariance, compress_gaussians,  # noqa: F401
+                 join_features, vq_features, weightedDistance)
+
+__version__ = "0.1.0"
+
+
+def install_as_reference_modules():
+    """Register this package under the module names the reference imports
+    (scene/gaussian_model.py:43-44, compression/vq.py:12), so the reference's Python runs unmodified."""
+    for name in ("diff_gaussian_rasterization_no_camera", "diff_gaussian_rasterization",
+                 "diff_gaussian_rasterization_camera"):
+        sys.modules[name] = rasterizer
+    wd = types.ModuleType("weighted_distance")
+    wdc = types.ModuleType("weighted_distance._C")
+    wdc.weightedDistance = lambda coefs, codebook: weightedDistance(coefs, codebook)
+    wd._C = wdc
+    sys.modules["weighted_distance"] = wd
+    sys.modules["weighted_distance._C"] = wdc

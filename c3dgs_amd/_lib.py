@@ -1,0 +1,104 @@
+"""ctypes binding of libc3dgs_hip.so (include/c3dgs_hip.h).  No CPU fallback: if the HIP library is
+missing or cannot be loaded, importing any op raises immediately."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libc3dgs_hip.so")
+
+_f32p = C.POINTER(C.c_float)
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+
+RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class RasterParams(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+        ("SHS", C.c_int32), ("GS", C.c_int32),
+        ("background", C.c_void_p), ("means3D", C.c_void_p), ("sh", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("opacities", C.c_void_p), ("scales", C.c_void_p), ("scale_factors", C.c_void_p), ("rotations", C.c_void_p),
+        ("cov3D_precomp", C.c_void_p), ("sh_indices", C.c_void_p), ("g_indices", C.c_void_p),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+        ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("scale_modifier", C.c_float),
+        ("prefiltered", C.c_int32), ("clamp_color", C.c_int32), ("debug", C.c_int32),
+    ]
+
+
+class RasterGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+        "dL_dscale_factors", "dL_drotations")]
+
+
+class GeomLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in (
+        "total_bytes", "splat", "depths", "tiles_touched", "point_offsets", "rects", "clamped", "scan_temp",
+        "scan_temp_bytes")]
+
+
+class BinningLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in (
+        "total_bytes", "keys_unsorted", "values_unsorted", "keys_sorted", "point_list", "sort_temp", "sort_temp_bytes")]
+
+
+class ImageLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("total_bytes", "final_T", "n_contrib", "ranges", "tile_used")]
+
+
+# name -> (restype, argtypes); every symbol include/c3dgs_hip.h declares
+PROTOTYPES = {
+    "c3dgs_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c3dgs_rasterize_gaussians": (C.c_int, [C.POINTER(RasterParams), RESIZE_FN, C.c_void_p, RESIZE_FN, C.c_void_p,
+                                            RESIZE_FN, C.c_void_p, C.c_void_p, C.c_void_p, _i32p, C.c_void_p]),
+    "c3dgs_rasterize_gaussians_indexed": (C.c_int, [C.POINTER(RasterParams), RESIZE_FN, C.c_void_p, RESIZE_FN, C.c_void_p,
+                                                    RESIZE_FN, C.c_void_p, C.c_void_p, C.c_void_p, _i32p, C.c_void_p]),
+    "c3dgs_rasterize_gaussians_backward": (C.c_int, [C.POINTER(RasterParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_int32, C.c_void_p, RESIZE_FN, C.c_void_p,
+                                                     C.POINTER(RasterGrads), C.c_void_p]),
+    "c3dgs_rasterize_gaussians_backward_indexed": (C.c_int, [C.POINTER(RasterParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                             C.c_void_p, C.c_int32, C.c_void_p, RESIZE_FN, C.c_void_p,
+                                                             C.POINTER(RasterGrads), C.c_void_p]),
+    "c3dgs_weighted_distance": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    "c3dgs_vq_accumulate": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c3dgs_vq_apply": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                 C.c_int32, C.c_void_p]),
+    "c3dgs_get_geom_layout": (C.c_int, [C.c_int32, C.POINTER(GeomLayout)]),
+    "c3dgs_get_binning_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(BinningLayout)]),
+    "c3dgs_get_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(ImageLayout)]),
+    "c3dgs_backward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "c3dgs_last_error": (C.c_char_p, []),
+    "c3dgs_abi_version": (C.c_int, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once). Raises RuntimeError loudly when it is absent: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"c3dgs_amd: {LIB_PATH} is missing. Build it with `python -m c3dgs_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for this package.")
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise RuntimeError(f"c3dgs_amd: cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().c3dgs_last_error()
+        raise RuntimeError((msg or b"unknown error").decode("utf-8", "replace"))

@@ -1,0 +1,72 @@
+"""Build c3dgs_amd/libc3dgs_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m c3dgs_amd.build [--force] [--verbose]
+
+Per-file flags matter: preprocess.hip / backward_preprocess.hip are compiled with -ffp-contract=off
+because radii, tile rectangles and depth bits feed bit-exact integer tile keys (see csrc/gsmath.hpp).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libc3dgs_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+          "-fno-gpu-rdc", "-DNDEBUG"]
+SOURCES = {
+    "c_abi.hip": [],
+    "preprocess.hip": ["-ffp-contract=off"],
+    "backward_preprocess.hip": ["-ffp-contract=off"],
+    "binning.hip": [],
+    "render.hip": [],
+    "vq.hip": [],
+}
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gsmath.hpp"),
+           os.path.join(HERE, "..", "include", "c3dgs_hip.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(name, extra, verbose):
+    src = os.path.join(CSRC, name)
+    obj = os.path.join(OBJ, name.replace(".hip", ".o"))
+    cmd = [HIPCC] + COMMON + extra + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return obj
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    deps_common = HEADERS + [os.path.abspath(__file__)]
+    todo, objs = [], []
+    for name, extra in SOURCES.items():
+        obj = os.path.join(OBJ, name.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [os.path.join(CSRC, name)] + deps_common):
+            todo.append((name, extra))
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(4, len(todo))) as ex:
+            list(ex.map(lambda t: _compile(t[0], t[1], verbose), todo))
+    if force or todo or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))

@@ -1,0 +1,340 @@
+// backward_preprocess.hip -- per-Gaussian backward for gfx950: ONE kernel that
+//   (a) sums the Gaussian's contiguous run of per-tile partial sums written by render_backward_kernel,
+//   (b) K11  computeCov2DCUDA        reference cuda_rasterizer/backward.cu:144-274,
+//   (c) K12  BACKWARD::preprocessCUDA reference backward.cu:346-396 (+ computeColorFromSH :20-139,
+//            computeCov3D :278-341), K12i reference backward_indexed.cu:20-342.
+// It writes EVERY element of the P-sized outputs (zeros for culled Gaussians), so the caller needs
+// no zero-fill of those (the reference memsets ~0.9 GB per call at P=3M, rasterize_points.cu:153-162).
+// Only the codebook-sized outputs of the indexed variant are accumulated with fp32 atomics
+// (pre-zeroed by the C-ABI entry point); atomicAdd(float*) is a single global_atomic_add_f32 on gfx950.
+// 3D covariances are recomputed from scale/rotation instead of being stored by the forward.
+#include "common.hpp"
+#include "gsmath.hpp"
+
+namespace c3dgs {
+
+struct BwdArgs {
+    int P, D, M, W, H;
+    const float* means3D; const float* sh; const float* scales; const float* scale_factors; const float* rotations;
+    const float* cov3D_precomp; const int64_t* sh_indices; const int64_t* g_indices;
+    const float* view; const float* proj; const float* campos;
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+    const int32_t* radii; const uint32_t* tiles_touched; const uint32_t* point_offsets; const uint8_t* clamped;
+    const float* partials;
+    c3dgs_raster_grads g;
+};
+
+template <bool ATOMIC>
+__device__ __forceinline__ void emit(float* p, float v)
+{
+    if (ATOMIC) atomicAdd(p, v); else *p = v;
+}
+
+// SH backward. c = this Gaussian's coefficients; dst = gradient row (direct store or atomic scatter).
+template <int DEG, bool ATOMIC>
+__device__ __forceinline__ void sh_backward(const float* c, float* dst, int M, const f3 d0, const float g[3], float dmean_add[3])
+{
+    const float len = sqrtf(d0.x * d0.x + d0.y * d0.y + d0.z * d0.z);
+    const float x = d0.x / len, y = d0.y / len, z = d0.z / len;
+    float dx[3] = { 0, 0, 0 }, dy[3] = { 0, 0, 0 }, dz[3] = { 0, 0, 0 };
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    float basis[NB];
+    basis[0] = SH_C0;
+    if (DEG > 0) {
+        basis[1] = -SH_C1 * y; basis[2] = SH_C1 * z; basis[3] = -SH_C1 * x;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            dx[ch] = -SH_C1 * c[3 * 3 + ch];
+            dy[ch] = -SH_C1 * c[1 * 3 + ch];
+            dz[ch] = SH_C1 * c[2 * 3 + ch];
+        }
+    }
+    if (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        basis[4] = SH_C2_0 * xy; basis[5] = SH_C2_1 * yz; basis[6] = SH_C2_2 * (2.f * zz - xx - yy);
+        basis[7] = SH_C2_3 * xz; basis[8] = SH_C2_4 * (xx - yy);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float s4 = c[4 * 3 + ch], s5 = c[5 * 3 + ch], s6 = c[6 * 3 + ch], s7 = c[7 * 3 + ch], s8 = c[8 * 3 + ch];
+            dx[ch] += SH_C2_0 * y * s4 + SH_C2_2 * 2.f * -x * s6 + SH_C2_3 * z * s7 + SH_C2_4 * 2.f * x * s8;
+            dy[ch] += SH_C2_0 * x * s4 + SH_C2_1 * z * s5 + SH_C2_2 * 2.f * -y * s6 + SH_C2_4 * 2.f * -y * s8;
+            dz[ch] += SH_C2_1 * y * s5 + SH_C2_2 * 2.f * 2.f * z * s6 + SH_C2_3 * x * s7;
+        }
+        if (DEG > 2) {
+            basis[9] = SH_C3_0 * y * (3.f * xx - yy);
+            basis[10] = SH_C3_1 * xy * z;
+            basis[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+            basis[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+            basis[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+            basis[14] = SH_C3_5 * z * (xx - yy);
+            basis[15] = SH_C3_6 * x * (xx - 3.f * yy);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float s9 = c[9 * 3 + ch], s10 = c[10 * 3 + ch], s11 = c[11 * 3 + ch], s12 = c[12 * 3 + ch],
+                            s13 = c[13 * 3 + ch], s14 = c[14 * 3 + ch], s15 = c[15 * 3 + ch];
+                dx[ch] += SH_C3_0 * s9 * 3.f * 2.f * xy + SH_C3_1 * s10 * yz + SH_C3_2 * s11 * -2.f * xy +
+                          SH_C3_3 * s12 * -3.f * 2.f * xz + SH_C3_4 * s13 * (-3.f * xx + 4.f * zz - yy) +
+                          SH_C3_5 * s14 * 2.f * xz + SH_C3_6 * s15 * 3.f * (xx - yy);
+                dy[ch] += SH_C3_0 * s9 * 3.f * (xx - yy) + SH_C3_1 * s10 * xz + SH_C3_2 * s11 * (-3.f * yy + 4.f * zz - xx) +
+                          SH_C3_3 * s12 * -3.f * 2.f * yz + SH_C3_4 * s13 * -2.f * xy + SH_C3_5 * s14 * -2.f * yz +
+                          SH_C3_6 * s15 * -3.f * 2.f * xy;
+                dz[ch] += SH_C3_1 * s10 * xy + SH_C3_2 * s11 * 4.f * 2.f * yz + SH_C3_3 * s12 * 3.f * (2.f * zz - xx - yy) +
+                          SH_C3_4 * s13 * 4.f * 2.f * xz + SH_C3_5 * s14 * (xx - yy);
+            }
+        }
+    }
+    if (dst) {
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) emit<ATOMIC>(dst + k * 3 + ch, basis[k] * g[ch]);
+        if (!ATOMIC)                       // coefficients above the active degree get an explicit zero
+            for (int k = NB * 3; k < M * 3; k++) dst[k] = 0.f;
+    }
+    const float ddx = dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2];
+    const float ddy = dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2];
+    const float ddz = dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2];
+    // dnormvdv, auxiliary.h:107-117
+    const float sum2 = d0.x * d0.x + d0.y * d0.y + d0.z * d0.z;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    dmean_add[0] = ((+sum2 - d0.x * d0.x) * ddx - d0.y * d0.x * ddy - d0.z * d0.x * ddz) * invsum32;
+    dmean_add[1] = (-d0.x * d0.y * ddx + (sum2 - d0.y * d0.y) * ddy - d0.z * d0.y * ddz) * invsum32;
+    dmean_add[2] = (-d0.x * d0.z * ddx - d0.y * d0.z * ddy + (sum2 - d0.z * d0.z) * ddz) * invsum32;
+}
+
+template <int DEG, bool INDEXED>
+__global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.P) return;
+    const size_t si = (size_t)i;
+    const c3dgs_raster_grads& o = a.g;
+
+    if (!(a.radii[i] > 0)) {               // culled: the reference leaves its zero-filled rows untouched
+        if (o.dL_dmeans2D) { o.dL_dmeans2D[3 * si] = 0.f; o.dL_dmeans2D[3 * si + 1] = 0.f; o.dL_dmeans2D[3 * si + 2] = 0.f; }
+        if (o.dL_dcolors) { o.dL_dcolors[3 * si] = 0.f; o.dL_dcolors[3 * si + 1] = 0.f; o.dL_dcolors[3 * si + 2] = 0.f; }
+        if (o.dL_dopacity) o.dL_dopacity[si] = 0.f;
+        if (o.dL_dmeans3D) { o.dL_dmeans3D[3 * si] = 0.f; o.dL_dmeans3D[3 * si + 1] = 0.f; o.dL_dmeans3D[3 * si + 2] = 0.f; }
+        if (o.dL_dcov3D) for (int q = 0; q < 6; q++) o.dL_dcov3D[6 * si + q] = 0.f;
+        if (o.dL_dscale_factors) o.dL_dscale_factors[si] = 0.f;
+        if (!INDEXED) {
+            if (o.dL_dsh && a.sh) for (int q = 0; q < a.M * 3; q++) o.dL_dsh[si * a.M * 3 + q] = 0.f;
+            if (o.dL_dscales && a.scales) for (int q = 0; q < 3; q++) o.dL_dscales[3 * si + q] = 0.f;
+            if (o.dL_drotations && a.scales) for (int q = 0; q < 4; q++) o.dL_drotations[4 * si + q] = 0.f;
+        }
+        return;
+    }
+
+    // ---- (a) sum this Gaussian's per-tile partials: slots [offset_excl, offset_excl + tiles_touched)
+    const uint32_t off0 = (i == 0) ? 0u : a.point_offsets[i - 1];
+    const uint32_t cntp = a.tiles_touched[i];
+    float acc[PARTIAL_FLOATS];
+#pragma unroll
+    for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] = 0.f;
+    for (uint32_t s = 0; s < cntp; s++) {
+        const float* src = a.partials + (size_t)(off0 + s) * PARTIAL_FLOATS;
+#pragma unroll
+        for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] += src[q];
+    }
+    const float dcol[3] = { acc[0], acc[1], acc[2] };
+    const float d2x = acc[3], d2y = acc[4];
+    const float dcon_x = acc[5], dcon_y = acc[6], dcon_w = acc[7];
+    if (o.dL_dcolors) { o.dL_dcolors[3 * si] = dcol[0]; o.dL_dcolors[3 * si + 1] = dcol[1]; o.dL_dcolors[3 * si + 2] = dcol[2]; }
+    if (o.dL_dmeans2D) { o.dL_dmeans2D[3 * si] = d2x; o.dL_dmeans2D[3 * si + 1] = d2y; o.dL_dmeans2D[3 * si + 2] = 0.f; }
+    if (o.dL_dopacity) o.dL_dopacity[si] = acc[8];
+
+    const f3 m = { a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2] };
+
+    // ---- (b) conic -> cov2D -> cov3D / mean (backward.cu:144-274) in matrix form:
+    // A = upper 2x3 of J*R_w2c (reference T[i][j] == A[i][j]); cov2D = A*Sigma*A^T + 0.3*I.
+    float cov3D[6];
+    float sc[3] = { 0, 0, 0 }, sf = 1.f;
+    float4 rot = make_float4(1, 0, 0, 0);
+    size_t gi = si;
+    if (a.cov3D_precomp) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) cov3D[q] = a.cov3D_precomp[6 * si + q];
+    } else {
+        if (INDEXED) { gi = (size_t)a.g_indices[i]; sf = a.scale_factors[i]; }
+        sc[0] = a.scales[3 * gi]; sc[1] = a.scales[3 * gi + 1]; sc[2] = a.scales[3 * gi + 2];
+        rot = *reinterpret_cast<const float4*>(a.rotations + 4 * gi);
+        cov3d_from_scale_rot(sc[0], sc[1], sc[2], INDEXED ? sf * a.scale_modifier : a.scale_modifier, rot, cov3D);
+    }
+    const Cov2D cv = cov2d(m, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.view);
+    const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+    const float x_grad_mul = (cv.txtz < -limx || cv.txtz > limx) ? 0.f : 1.f;
+    const float y_grad_mul = (cv.tytz < -limy || cv.tytz > limy) ? 0.f : 1.f;
+    const float A[2][3] = { { cv.T.c[0][0], cv.T.c[0][1], cv.T.c[0][2] }, { cv.T.c[1][0], cv.T.c[1][1], cv.T.c[1][2] } };
+    const float Sg[3][3] = { { cov3D[0], cov3D[1], cov3D[2] }, { cov3D[1], cov3D[3], cov3D[4] }, { cov3D[2], cov3D[4], cov3D[5] } };
+    const float ca = cv.a, cb = cv.b, cc = cv.c;
+    const float denom = ca * cc - cb * cb;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dcov[6] = { 0, 0, 0, 0, 0, 0 };
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-cc * cc * dcon_x + 2 * cb * cc * dcon_y + (denom - ca * cc) * dcon_w);
+        dL_dc = denom2inv * (-ca * ca * dcon_w + 2 * ca * cb * dcon_y + (denom - ca * cc) * dcon_x);
+        dL_db = denom2inv * 2 * (cb * cc * dcon_x - (denom + 2 * cb * cb) * dcon_y + ca * cb * dcon_w);
+        const float Gm[2][2] = { { dL_da, 0.5f * dL_db }, { 0.5f * dL_db, dL_dc } };
+        float S3[3][3];
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+#pragma unroll
+            for (int v = u; v < 3; v++) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int w = 0; w < 2; w++) s += A[q][u] * Gm[q][w] * A[w][v];
+                S3[u][v] = s;
+            }
+        dcov[0] = S3[0][0]; dcov[3] = S3[1][1]; dcov[5] = S3[2][2];
+        dcov[1] = 2.f * S3[0][1]; dcov[2] = 2.f * S3[0][2]; dcov[4] = 2.f * S3[1][2];
+    }
+    if (o.dL_dcov3D)
+#pragma unroll
+        for (int q = 0; q < 6; q++) o.dL_dcov3D[6 * si + q] = dcov[q];
+
+    float AS[2][3], dA[2][3];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int v = 0; v < 3; v++) AS[q][v] = A[q][0] * Sg[0][v] + A[q][1] * Sg[1][v] + A[q][2] * Sg[2][v];
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        dA[0][v] = 2 * AS[0][v] * dL_da + AS[1][v] * dL_db;
+        dA[1][v] = 2 * AS[1][v] * dL_dc + AS[0][v] * dL_db;
+    }
+    const float* view = a.view;
+    const float dJ00 = view[0] * dA[0][0] + view[4] * dA[0][1] + view[8] * dA[0][2];
+    const float dJ02 = view[2] * dA[0][0] + view[6] * dA[0][1] + view[10] * dA[0][2];
+    const float dJ11 = view[1] * dA[1][0] + view[5] * dA[1][1] + view[9] * dA[1][2];
+    const float dJ12 = view[2] * dA[1][0] + view[6] * dA[1][1] + view[10] * dA[1][2];
+    const float tz = 1.f / cv.t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = x_grad_mul * -a.focal_x * tz2 * dJ02;
+    const float dty = y_grad_mul * -a.focal_y * tz2 * dJ12;
+    const float dtz = -a.focal_x * tz2 * dJ00 - a.focal_y * tz2 * dJ11 + (2 * a.focal_x * cv.t.x) * tz3 * dJ02 +
+                      (2 * a.focal_y * cv.t.y) * tz3 * dJ12;
+    float dmean[3] = { view[0] * dtx + view[1] * dty + view[2] * dtz,
+                       view[4] * dtx + view[5] * dty + view[6] * dtz,
+                       view[8] * dtx + view[9] * dty + view[10] * dtz };
+
+    // ---- (c) projection of the 2D mean (backward.cu:370-387)
+    const float* proj = a.proj;
+    const float4 mh = xform4x4(m, proj);
+    const float m_w = 1.0f / (mh.w + 0.0000001f);
+    const float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
+    const float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
+    dmean[0] += (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
+    dmean[1] += (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
+    dmean[2] += (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
+
+    // ---- SH (backward.cu:20-139 / backward_indexed.cu:20-201)
+    if (a.sh) {
+        const size_t row = INDEXED ? (size_t)a.sh_indices[i] : si;
+        const float* shp = a.sh + row * (size_t)a.M * 3;
+        constexpr int NC = (DEG + 1) * (DEG + 1) * 3;
+        float c[NC];
+        if ((a.M * 3) % 4 == 0 && NC % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < NC / 4; q++) {
+                const float4 v = reinterpret_cast<const float4*>(shp)[q];
+                c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NC; q++) c[q] = shp[q];
+        }
+        const uint8_t cl = a.clamped[i];
+        const float g[3] = { (cl & 1) ? 0.f : dcol[0], (cl & 2) ? 0.f : dcol[1], (cl & 4) ? 0.f : dcol[2] };
+        const f3 d0 = { m.x - a.campos[0], m.y - a.campos[1], m.z - a.campos[2] };
+        float add[3];
+        float* dst = o.dL_dsh ? o.dL_dsh + row * (size_t)a.M * 3 : nullptr;
+        sh_backward<DEG, INDEXED>(c, dst, a.M, d0, g, add);
+        dmean[0] += add[0]; dmean[1] += add[1]; dmean[2] += add[2];
+    }
+    if (o.dL_dmeans3D) { o.dL_dmeans3D[3 * si] = dmean[0]; o.dL_dmeans3D[3 * si + 1] = dmean[1]; o.dL_dmeans3D[3 * si + 2] = dmean[2]; }
+
+    // ---- scale / rotation (backward.cu:278-341 / backward_indexed.cu:206-282), against the standard
+    // rotation matrix Rm: L = Rm*diag(s), Sigma = L*L^T, dL/dL = 2*G*L.
+    if (a.scales) {
+        const float s[3] = { (INDEXED ? sf * a.scale_modifier : a.scale_modifier) * sc[0],
+                             (INDEXED ? sf * a.scale_modifier : a.scale_modifier) * sc[1],
+                             (INDEXED ? sf * a.scale_modifier : a.scale_modifier) * sc[2] };
+        const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
+        const float Rm[3][3] = { { 1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y) },
+                                 { 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x) },
+                                 { 2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y) } };
+        const float G3[3][3] = { { dcov[0], 0.5f * dcov[1], 0.5f * dcov[2] },
+                                 { 0.5f * dcov[1], dcov[3], 0.5f * dcov[4] },
+                                 { 0.5f * dcov[2], 0.5f * dcov[4], dcov[5] } };
+        float Q[3][3], d_s[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float col[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float accv = 0.f;
+#pragma unroll
+                for (int q = 0; q < 3; q++) accv += G3[k][q] * (Rm[q][j] * s[j]);
+                col[k] = 2.0f * accv;
+            }
+            d_s[j] = Rm[0][j] * col[0] + Rm[1][j] * col[1] + Rm[2][j] * col[2];
+#pragma unroll
+            for (int k = 0; k < 3; k++) Q[k][j] = col[k] * s[j];
+        }
+        float dq[4];
+        dq[0] = 2 * z * (Q[1][0] - Q[0][1]) + 2 * y * (Q[0][2] - Q[2][0]) + 2 * x * (Q[2][1] - Q[1][2]);
+        dq[1] = 2 * y * (Q[0][1] + Q[1][0]) + 2 * z * (Q[0][2] + Q[2][0]) + 2 * r * (Q[2][1] - Q[1][2]) - 4 * x * (Q[2][2] + Q[1][1]);
+        dq[2] = 2 * x * (Q[0][1] + Q[1][0]) + 2 * r * (Q[0][2] - Q[2][0]) + 2 * z * (Q[2][1] + Q[1][2]) - 4 * y * (Q[2][2] + Q[0][0]);
+        dq[3] = 2 * r * (Q[1][0] - Q[0][1]) + 2 * x * (Q[0][2] + Q[2][0]) + 2 * y * (Q[2][1] + Q[1][2]) - 4 * z * (Q[1][1] + Q[0][0]);
+        if (INDEXED) {                       // backward_indexed.cu:255-262, 276-281
+            if (o.dL_dscales)
+#pragma unroll
+                for (int q = 0; q < 3; q++) atomicAdd(o.dL_dscales + 3 * gi + q, d_s[q] * sf);
+            if (o.dL_dscale_factors) o.dL_dscale_factors[si] = d_s[0] * sc[0] + d_s[1] * sc[1] + d_s[2] * sc[2];
+            if (o.dL_drotations)
+#pragma unroll
+                for (int q = 0; q < 4; q++) atomicAdd(o.dL_drotations + 4 * gi + q, dq[q]);
+        } else {
+            if (o.dL_dscales) { o.dL_dscales[3 * si] = d_s[0]; o.dL_dscales[3 * si + 1] = d_s[1]; o.dL_dscales[3 * si + 2] = d_s[2]; }
+            if (o.dL_drotations) *reinterpret_cast<float4*>(o.dL_drotations + 4 * si) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        }
+    } else if (INDEXED && o.dL_dscale_factors) {
+        o.dL_dscale_factors[si] = 0.f;
+    }
+}
+
+void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* radii, const GeomPtrs& g,
+                                const float* partials, const c3dgs_raster_grads& gr, hipStream_t s)
+{
+    if (p.P <= 0) return;
+    BwdArgs a;
+    a.P = p.P; a.D = p.D; a.M = p.M; a.W = p.W; a.H = p.H;
+    a.means3D = p.means3D; a.sh = p.sh; a.scales = p.scales; a.scale_factors = p.scale_factors; a.rotations = p.rotations;
+    a.cov3D_precomp = p.cov3D_precomp; a.sh_indices = p.sh_indices; a.g_indices = p.g_indices;
+    a.view = p.viewmatrix; a.proj = p.projmatrix; a.campos = p.campos;
+    a.tan_fovx = p.tan_fovx; a.tan_fovy = p.tan_fovy;
+    a.focal_y = p.H / (2.0f * p.tan_fovy);
+    a.focal_x = p.W / (2.0f * p.tan_fovx);
+    a.scale_modifier = p.scale_modifier;
+    a.radii = radii; a.tiles_touched = g.tiles_touched; a.point_offsets = g.point_offsets; a.clamped = g.clamped;
+    a.partials = partials; a.g = gr;
+    const dim3 grid((p.P + 255) / 256), block(256);
+    const bool indexed = p.sh_indices != nullptr || p.g_indices != nullptr;
+    const int deg = p.sh ? p.D : 0;
+#define C3DGS_LAUNCH(DEG)                                                                     \
+    do {                                                                                      \
+        if (indexed) backward_preprocess_kernel<DEG, true><<<grid, block, 0, s>>>(a);         \
+        else backward_preprocess_kernel<DEG, false><<<grid, block, 0, s>>>(a);                \
+    } while (0)
+    switch (deg) {
+        case 0: C3DGS_LAUNCH(0); break;
+        case 1: C3DGS_LAUNCH(1); break;
+        case 2: C3DGS_LAUNCH(2); break;
+        default: C3DGS_LAUNCH(3); break;
+    }
+#undef C3DGS_LAUNCH
+}
+
+} // namespace c3dgs

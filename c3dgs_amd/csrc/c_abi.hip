@@ -1,0 +1,254 @@
+// c_abi.hip -- extern "C" entry points of libc3dgs_hip.so (declared in include/c3dgs_hip.h).
+// Stage order follows the reference's Rasterizer::forward / backward (cuda_rasterizer/rasterizer_impl.cu:194-334,
+// 338-435, 440-586, 590-697); the stages themselves are the gfx950 kernels in this directory.
+#include "common.hpp"
+
+namespace c3dgs {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+static int validate(const c3dgs_raster_params* p, bool indexed, bool is_backward)
+{
+    if (!p) return fail(C3DGS_E_INVALID, "params is NULL");
+    if (p->P < 0 || p->W <= 0 || p->H <= 0) return fail(C3DGS_E_INVALID, "P, W, H must be non-negative / positive");
+    if (p->P == 0) return C3DGS_OK;
+    if (!p->means3D) return fail(C3DGS_E_INVALID, "means3D must have dimensions (num_points, 3)"); // rasterize_points.cu:58-60
+    if (!p->background || !p->viewmatrix || !p->projmatrix || !p->campos)
+        return fail(C3DGS_E_INVALID, "background, viewmatrix, projmatrix and campos are required");
+    if (!is_backward && !p->opacities) // the backward reads opacities from the geometry buffer, as the reference does
+        return fail(C3DGS_E_INVALID, "opacities is required");
+    if ((p->sh == nullptr) == (p->colors_precomp == nullptr))
+        return fail(C3DGS_E_INVALID, "Please provide excatly one of either SHs or precomputed colors!");
+    const bool has_sr = p->scales != nullptr && p->rotations != nullptr;
+    if ((p->scales != nullptr) != (p->rotations != nullptr) || has_sr == (p->cov3D_precomp != nullptr))
+        return fail(C3DGS_E_INVALID, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (p->sh) {
+        if (p->D < 0 || p->D > 3) return fail(C3DGS_E_INVALID, "SH degree must be in [0,3]");
+        if (p->M < (p->D + 1) * (p->D + 1)) return fail(C3DGS_E_INVALID, "sh has fewer coefficients than the active degree needs");
+    }
+    if (indexed) {
+        if (p->sh && !p->sh_indices) return fail(C3DGS_E_INVALID, "indexed rasterizer: sh_indices is required with sh");
+        if (has_sr && (!p->g_indices || !p->scale_factors))
+            return fail(C3DGS_E_INVALID, "indexed rasterizer: g_indices and scale_factors are required with scales/rotations");
+    } else if (p->sh_indices || p->g_indices || p->scale_factors) {
+        return fail(C3DGS_E_INVALID, "non-indexed rasterizer: sh_indices / g_indices / scale_factors must be NULL");
+    }
+    if (tiles_x(p->W) > 65535 || tiles_y(p->H) > 65535) return fail(C3DGS_E_INVALID, "image too large for 16-bit tile coordinates");
+    return C3DGS_OK;
+}
+
+static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resize_fn geom_resize, void* geom_user,
+                        c3dgs_resize_fn binning_resize, void* binning_user, c3dgs_resize_fn image_resize, void* image_user,
+                        float* out_color, int32_t* radii, int32_t* num_rendered, void* stream_)
+{
+    if (int rc = validate(pp, indexed, false)) return rc;
+    if (!out_color || !num_rendered) return fail(C3DGS_E_INVALID, "out_color and num_rendered are required");
+    if (!geom_resize || !binning_resize || !image_resize) return fail(C3DGS_E_INVALID, "resize callbacks are required");
+    c3dgs_raster_params p = *pp;
+    if (!indexed) { p.sh_indices = nullptr; p.g_indices = nullptr; p.scale_factors = nullptr; }
+    hipStream_t s = (hipStream_t)stream_;
+    const int P = p.P, W = p.W, H = p.H;
+    const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
+    *num_rendered = 0;
+
+    c3dgs_image_layout IL; image_layout(W, H, &IL);
+    void* img_base = image_resize(image_user, IL.total_bytes);
+    if (!img_base) return fail(C3DGS_E_ALLOC, "image buffer allocation failed");
+    const ImgPtrs img = img_ptrs(img_base, W, H);
+
+    if (P == 0) { // reference returns zero-filled outputs (rasterize_points.cu:69-70,82)
+        C3DGS_HIP_TRY(hipMemsetAsync(out_color, 0, (size_t)3 * W * H * sizeof(float), s));
+        return C3DGS_OK;
+    }
+    if (!radii) return fail(C3DGS_E_INVALID, "radii is required");
+
+    c3dgs_geom_layout GL; geom_layout(P, &GL);
+    void* geom_base = geom_resize(geom_user, GL.total_bytes);
+    if (!geom_base) return fail(C3DGS_E_ALLOC, "geometry buffer allocation failed");
+    const GeomPtrs g = geom_ptrs(geom_base, P);
+
+    launch_preprocess(p, g, radii, s);                                               // K2 / K2i
+    C3DGS_STAGE("preprocess", p.debug, s);
+    C3DGS_HIP_TRY(run_inclusive_scan(g.scan_temp, g.scan_temp_bytes, g.tiles_touched, g.point_offsets, P, s)); // K3
+    C3DGS_STAGE("scan", p.debug, s);
+    uint32_t R_u = 0;                                                                // K4: the one host sync
+    C3DGS_HIP_TRY(hipMemcpyAsync(&R_u, g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    C3DGS_HIP_TRY(hipStreamSynchronize(s));
+    if (R_u > 0x7fffffffu) return fail(C3DGS_E_INVALID, "num_rendered overflows int32");
+    const int R = (int)R_u;
+    *num_rendered = R;
+
+    c3dgs_binning_layout BL; binning_layout(R, W, H, &BL);
+    void* bin_base = binning_resize(binning_user, BL.total_bytes);
+    if (!bin_base) return fail(C3DGS_E_ALLOC, "binning buffer allocation failed");
+    const BinPtrs b = bin_ptrs(bin_base, R, W, H);
+
+    C3DGS_HIP_TRY(hipMemsetAsync(img.ranges, 0, (size_t)T * sizeof(uint2), s));      // K7
+    if (R > 0) {
+        launch_duplicate_with_keys(P, g, radii, b, gx, s);                           // K5
+        C3DGS_STAGE("duplicate_with_keys", p.debug, s);
+        const int end_bit = 32 + (int)higher_msb((uint32_t)T);
+        C3DGS_HIP_TRY(run_sort_pairs(b.sort_temp, b.sort_temp_bytes, b.keys_unsorted, b.keys_sorted, b.values_unsorted,
+                                     b.point_list, R, end_bit, s));                  // K6
+        C3DGS_STAGE("sort", p.debug, s);
+        launch_identify_ranges(R, b.keys_sorted, img.ranges, s);                     // K8
+        C3DGS_STAGE("identify_ranges", p.debug, s);
+    }
+    launch_render_forward(W, H, img, b.point_list, g.splat, nullptr, p.background, out_color, s); // K9
+    C3DGS_STAGE("render_forward", p.debug, s);
+    return C3DGS_OK;
+}
+
+static int backward_impl(const c3dgs_raster_params* pp, bool indexed, const int32_t* radii, const void* geom_buffer,
+                         const void* binning_buffer, const void* image_buffer, int32_t R, const float* dL_dout_color,
+                         c3dgs_resize_fn ws_resize, void* ws_user, const c3dgs_raster_grads* grads, void* stream_)
+{
+    if (int rc = validate(pp, indexed, true)) return rc;
+    if (!grads) return fail(C3DGS_E_INVALID, "grads is NULL");
+    c3dgs_raster_params p = *pp;
+    if (!indexed) { p.sh_indices = nullptr; p.g_indices = nullptr; p.scale_factors = nullptr; }
+    hipStream_t s = (hipStream_t)stream_;
+    const int P = p.P, W = p.W, H = p.H;
+
+    // codebook-sized outputs of the indexed variant are scatter-added: zero them here
+    if (indexed) {
+        if (grads->dL_dsh && p.sh) C3DGS_HIP_TRY(hipMemsetAsync(grads->dL_dsh, 0, (size_t)p.SHS * p.M * 3 * sizeof(float), s));
+        if (grads->dL_dscales && p.scales) C3DGS_HIP_TRY(hipMemsetAsync(grads->dL_dscales, 0, (size_t)p.GS * 3 * sizeof(float), s));
+        if (grads->dL_drotations && p.scales) C3DGS_HIP_TRY(hipMemsetAsync(grads->dL_drotations, 0, (size_t)p.GS * 4 * sizeof(float), s));
+    }
+    if (P == 0) return C3DGS_OK;
+    if (!radii || !geom_buffer || !image_buffer || !dL_dout_color || (R > 0 && !binning_buffer))
+        return fail(C3DGS_E_INVALID, "radii, forward buffers and dL_dout_color are required");
+    if (!ws_resize) return fail(C3DGS_E_INVALID, "workspace callback is required");
+    if (R < 0) return fail(C3DGS_E_INVALID, "R must be >= 0");
+
+    const GeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
+    const ImgPtrs img = img_ptrs(const_cast<void*>(image_buffer), W, H);
+    const size_t ws_bytes = c3dgs_backward_workspace_bytes(P, R);
+    float* partials = (float*)ws_resize(ws_user, ws_bytes);
+    if (!partials) return fail(C3DGS_E_ALLOC, "backward workspace allocation failed");
+
+    C3DGS_HIP_TRY(hipMemsetAsync(partials, 0, ws_bytes, s));
+    if (R > 0) {
+        const BinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), R, W, H);
+        launch_render_backward(W, H, img, b.point_list, g.splat, nullptr, p.background, dL_dout_color, partials, s); // K10
+        C3DGS_STAGE("render_backward", p.debug, s);
+    }
+    launch_backward_preprocess(p, radii, g, partials, *grads, s);                    // K11 + K12(i)
+    C3DGS_STAGE("backward_preprocess", p.debug, s);
+    return C3DGS_OK;
+}
+
+} // namespace c3dgs
+
+using namespace c3dgs;
+
+extern "C" {
+
+const char* c3dgs_last_error(void) { return g_last_error.c_str(); }
+int c3dgs_abi_version(void) { return C3DGS_ABI_VERSION; }
+
+int c3dgs_get_geom_layout(int32_t P, c3dgs_geom_layout* out)
+{
+    if (!out || P < 0) return fail(C3DGS_E_INVALID, "bad arguments");
+    geom_layout(P, out);
+    return C3DGS_OK;
+}
+int c3dgs_get_binning_layout(int32_t R, int32_t W, int32_t H, c3dgs_binning_layout* out)
+{
+    if (!out || R < 0 || W <= 0 || H <= 0) return fail(C3DGS_E_INVALID, "bad arguments");
+    binning_layout(R, W, H, out);
+    return C3DGS_OK;
+}
+int c3dgs_get_image_layout(int32_t W, int32_t H, c3dgs_image_layout* out)
+{
+    if (!out || W <= 0 || H <= 0) return fail(C3DGS_E_INVALID, "bad arguments");
+    image_layout(W, H, out);
+    return C3DGS_OK;
+}
+size_t c3dgs_backward_workspace_bytes(int32_t P, int32_t R)
+{
+    (void)P;
+    return align_up((size_t)(R > 0 ? R : 1) * PARTIAL_FLOATS * sizeof(float));
+}
+
+int c3dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                       void* stream)
+{
+    (void)projmatrix; // the reference's in_frustum only tests view-space z (auxiliary.h:156)
+    if (P < 0) return fail(C3DGS_E_INVALID, "P must be >= 0");
+    if (P == 0) return C3DGS_OK;
+    if (!means3D || !viewmatrix || !present) return fail(C3DGS_E_INVALID, "means3D, viewmatrix and present are required");
+    launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+    C3DGS_STAGE("mark_visible", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_rasterize_gaussians(const c3dgs_raster_params* p, c3dgs_resize_fn geom_resize, void* geom_user,
+                              c3dgs_resize_fn binning_resize, void* binning_user, c3dgs_resize_fn image_resize,
+                              void* image_user, float* out_color, int32_t* radii, int32_t* num_rendered, void* stream)
+{
+    return forward_impl(p, false, geom_resize, geom_user, binning_resize, binning_user, image_resize, image_user, out_color,
+                        radii, num_rendered, stream);
+}
+
+int c3dgs_rasterize_gaussians_indexed(const c3dgs_raster_params* p, c3dgs_resize_fn geom_resize, void* geom_user,
+                                      c3dgs_resize_fn binning_resize, void* binning_user, c3dgs_resize_fn image_resize,
+                                      void* image_user, float* out_color, int32_t* radii, int32_t* num_rendered, void* stream)
+{
+    return forward_impl(p, true, geom_resize, geom_user, binning_resize, binning_user, image_resize, image_user, out_color,
+                        radii, num_rendered, stream);
+}
+
+int c3dgs_rasterize_gaussians_backward(const c3dgs_raster_params* p, const int32_t* radii, const void* geom_buffer,
+                                       const void* binning_buffer, const void* image_buffer, int32_t R,
+                                       const float* dL_dout_color, c3dgs_resize_fn workspace_resize, void* workspace_user,
+                                       const c3dgs_raster_grads* grads, void* stream)
+{
+    return backward_impl(p, false, radii, geom_buffer, binning_buffer, image_buffer, R, dL_dout_color, workspace_resize,
+                         workspace_user, grads, stream);
+}
+
+int c3dgs_rasterize_gaussians_backward_indexed(const c3dgs_raster_params* p, const int32_t* radii, const void* geom_buffer,
+                                               const void* binning_buffer, const void* image_buffer, int32_t R,
+                                               const float* dL_dout_color, c3dgs_resize_fn workspace_resize,
+                                               void* workspace_user, const c3dgs_raster_grads* grads, void* stream)
+{
+    return backward_impl(p, true, radii, geom_buffer, binning_buffer, image_buffer, R, dL_dout_color, workspace_resize,
+                         workspace_user, grads, stream);
+}
+
+int c3dgs_weighted_distance(int64_t N, int32_t C, int32_t K, const float* coefs, const int64_t* gather,
+                            const float* codebook, float* out_dist, int64_t* out_idx, void* stream)
+{
+    if (N < 0 || C < 0 || K <= 0) return fail(C3DGS_E_INVALID, "coefs and codebook must have same number of channels");
+    if (N == 0) return C3DGS_OK;
+    if (!coefs || !codebook || !out_dist || !out_idx) return fail(C3DGS_E_INVALID, "ceofs and codebook must have dimension 2");
+    if (launch_weighted_distance(N, C, K, coefs, gather, codebook, out_dist, out_idx, (hipStream_t)stream))
+        return fail(C3DGS_E_INVALID, "unsupported channel count");
+    C3DGS_STAGE("weighted_distance", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_vq_accumulate(int64_t B, int32_t K, int32_t D, const float* x, const float* w, const int64_t* gather,
+                        const int64_t* idx, const float* dist, float* S, double* dist_sum, void* stream)
+{
+    if (B < 0 || K <= 0 || D <= 0) return fail(C3DGS_E_INVALID, "bad sizes");
+    if (B == 0) return C3DGS_OK;
+    if (!x || !w || !idx || !S) return fail(C3DGS_E_INVALID, "x, w, idx and S are required");
+    launch_vq_accumulate(B, K, D, x, w, gather, idx, dist, S, dist_sum, (hipStream_t)stream);
+    C3DGS_STAGE("vq_accumulate", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_vq_apply(int32_t K, int32_t D, const float* S, float* codebook, float* entry_importance, float decay,
+                   float alpha, float eps, int32_t scale_normalize, void* stream)
+{
+    if (K <= 0 || D <= 0 || !S || !codebook || !entry_importance) return fail(C3DGS_E_INVALID, "bad arguments");
+    launch_vq_apply(K, D, S, codebook, entry_importance, decay, alpha, eps, scale_normalize, (hipStream_t)stream);
+    C3DGS_STAGE("vq_apply", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,157 @@
+// common.hpp -- shared host/device helpers for libc3dgs_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/c3dgs_hip.h"
+
+namespace c3dgs {
+
+constexpr int TILE = 16;          // reference BLOCK_X = BLOCK_Y = 16 (cuda_rasterizer/config.h:16-17)
+constexpr int TILE_PIX = 256;
+constexpr int SPLAT_F4 = 3;       // float4 per splat record (48 B)
+constexpr int PARTIAL_FLOATS = 9; // dcolor(3) dmean2D(2) dconic(3) dopacity(1) per (Gaussian,tile) instance
+
+// ---------------------------------------------------------------- errors
+void set_error(const std::string& msg);
+inline int fail(int code, const std::string& msg) { set_error(msg); return code; }
+
+#define C3DGS_HIP_TRY(expr)                                                                         \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return ::c3dgs::fail(C3DGS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));  \
+    } while (0)
+
+// after a kernel launch: always catch launch errors; with debug also synchronise (reference CHECK_CUDA,
+// cuda_rasterizer/auxiliary.h:168-175)
+#define C3DGS_STAGE(name, debug, stream)                                                            \
+    do {                                                                                            \
+        hipError_t e__ = hipGetLastError();                                                         \
+        if (e__ == hipSuccess && (debug)) e__ = hipStreamSynchronize(stream);                       \
+        if (e__ != hipSuccess)                                                                      \
+            return ::c3dgs::fail(C3DGS_E_HIP, std::string("stage ") + name + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// ---------------------------------------------------------------- scratch layouts
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+size_t scan_temp_bytes(int P);
+size_t sort_temp_bytes(int R, int end_bit);
+
+inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
+inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
+
+// reference getHigherMsb, rasterizer_impl.cu:35-50
+inline uint32_t higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4, step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+inline void geom_layout(int P, c3dgs_geom_layout* L)
+{
+    size_t o = 0, p = (size_t)(P > 0 ? P : 1);
+    L->splat = o;          o = align_up(o + p * SPLAT_F4 * 16);
+    L->depths = o;         o = align_up(o + p * 4);
+    L->tiles_touched = o;  o = align_up(o + p * 4);
+    L->point_offsets = o;  o = align_up(o + p * 4);
+    L->rects = o;          o = align_up(o + p * 8);
+    L->clamped = o;        o = align_up(o + p);
+    L->scan_temp = o;      L->scan_temp_bytes = scan_temp_bytes((int)p);
+    o = align_up(o + L->scan_temp_bytes);
+    L->total_bytes = o;
+}
+
+inline void binning_layout(int R, int W, int H, c3dgs_binning_layout* L)
+{
+    size_t o = 0, r = (size_t)(R > 0 ? R : 1);
+    int end_bit = 32 + (int)higher_msb((uint32_t)(tiles_x(W) * tiles_y(H)));
+    L->keys_unsorted = o;   o = align_up(o + r * 8);
+    L->values_unsorted = o; o = align_up(o + r * 4);
+    L->keys_sorted = o;     o = align_up(o + r * 8);
+    L->point_list = o;      o = align_up(o + r * 4);
+    L->sort_temp = o;       L->sort_temp_bytes = sort_temp_bytes((int)r, end_bit);
+    o = align_up(o + L->sort_temp_bytes);
+    L->total_bytes = o;
+}
+
+inline void image_layout(int W, int H, c3dgs_image_layout* L)
+{
+    size_t o = 0, n = (size_t)W * H, t = (size_t)tiles_x(W) * tiles_y(H);
+    L->final_T = o;   o = align_up(o + n * 4);
+    L->n_contrib = o; o = align_up(o + n * 4);
+    L->ranges = o;    o = align_up(o + t * 8);
+    L->tile_used = o; o = align_up(o + t * 4);
+    L->total_bytes = o;
+}
+
+// ---------------------------------------------------------------- kernel launchers (one per .hip file)
+struct GeomPtrs {
+    float4* splat; float* depths; uint32_t* tiles_touched; uint32_t* point_offsets; uint16_t* rects;
+    uint8_t* clamped; void* scan_temp; size_t scan_temp_bytes;
+};
+struct BinPtrs {
+    uint64_t* keys_unsorted; uint32_t* values_unsorted; uint64_t* keys_sorted; uint32_t* point_list;
+    void* sort_temp; size_t sort_temp_bytes;
+};
+struct ImgPtrs { float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_used; };
+
+inline GeomPtrs geom_ptrs(void* base, int P)
+{
+    c3dgs_geom_layout L; geom_layout(P, &L);
+    char* b = (char*)base;
+    return { (float4*)(b + L.splat), (float*)(b + L.depths), (uint32_t*)(b + L.tiles_touched),
+             (uint32_t*)(b + L.point_offsets), (uint16_t*)(b + L.rects), (uint8_t*)(b + L.clamped),
+             (void*)(b + L.scan_temp), L.scan_temp_bytes };
+}
+inline BinPtrs bin_ptrs(void* base, int R, int W, int H)
+{
+    c3dgs_binning_layout L; binning_layout(R, W, H, &L);
+    char* b = (char*)base;
+    return { (uint64_t*)(b + L.keys_unsorted), (uint32_t*)(b + L.values_unsorted), (uint64_t*)(b + L.keys_sorted),
+             (uint32_t*)(b + L.point_list), (void*)(b + L.sort_temp), L.sort_temp_bytes };
+}
+inline ImgPtrs img_ptrs(void* base, int W, int H)
+{
+    c3dgs_image_layout L; image_layout(W, H, &L);
+    char* b = (char*)base;
+    return { (float*)(b + L.final_T), (uint32_t*)(b + L.n_contrib), (uint2*)(b + L.ranges), (uint32_t*)(b + L.tile_used) };
+}
+
+// preprocess.hip
+void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, hipStream_t s);
+void launch_duplicate_with_keys(int P, const GeomPtrs& g, const int32_t* radii, const BinPtrs& b, int grid_x, hipStream_t s);
+void launch_identify_ranges(int R, const uint64_t* keys_sorted, uint2* ranges, hipStream_t s);
+// binning.hip
+hipError_t run_inclusive_scan(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, int P, hipStream_t s);
+hipError_t run_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
+                          uint32_t* vout, int R, int end_bit, hipStream_t s);
+// render.hip
+void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
+                           const float* colors_precomp, const float* bg, float* out_color, hipStream_t s);
+void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
+                            const float* colors_precomp, const float* bg, const float* dL_dpix, float* partials,
+                            hipStream_t s);
+// backward_preprocess.hip
+void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* radii, const GeomPtrs& g,
+                                const float* partials, const c3dgs_raster_grads& gr, hipStream_t s);
+// vq.hip
+int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const int64_t* gather, const float* codebook,
+                             float* out_dist, int64_t* out_idx, hipStream_t s);
+void launch_vq_accumulate(int64_t B, int K, int D, const float* x, const float* w, const int64_t* gather,
+                          const int64_t* idx, const float* dist, float* S, double* dist_sum, hipStream_t s);
+void launch_vq_apply(int K, int D, const float* S, float* codebook, float* entry_importance, float decay, float alpha,
+                     float eps, int scale_normalize, hipStream_t s);
+
+} // namespace c3dgs

@@ -1,0 +1,257 @@
+// preprocess.hip -- per-Gaussian forward stages for gfx950 (compiled with -ffp-contract=off).
+//
+//   K1  mark_visible        reference rasterizer_impl.cu:54-66 + auxiliary.h:139-166
+//   K2  preprocess          reference forward.cu:163-265   (K2i: forward_indexed.cu:162-268)
+//   K5  duplicate_with_keys reference rasterizer_impl.cu:70-111
+//   K8  identify_ranges     reference rasterizer_impl.cu:116-138
+//
+// Design notes (MI355X): one thread per Gaussian, 256-thread blocks (4 waves). The stage is
+// HBM-bound on the SH read (192 B of ~236 B per Gaussian at degree 3); culled Gaussians return
+// before touching SH. Everything the blend kernels need per Gaussian is packed into ONE 48-byte
+// record (3 x float4) so the per-tile gathers in render.hip touch a single cache line:
+//   rec[0] = {mean2D.x, mean2D.y, conic.a, conic.b}
+//   rec[1] = {conic.c, opacity, r, g}
+//   rec[2] = {b, bits(exclusive tile-instance offset), bits(x0|y0<<16), bits(x1|y1<<16)}
+// The last three words let the backward find the instance slot of (Gaussian, tile) without any
+// extra gather (see render.hip).
+#include "common.hpp"
+#include "gsmath.hpp"
+
+namespace c3dgs {
+
+__global__ void __launch_bounds__(256)
+mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view, uint8_t* __restrict__ present)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    f3 p = { means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2] };
+    f3 pv = xform4x3(p, view);
+    present[i] = !(pv.z <= 0.01f) ? 1 : 0;
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s)
+{
+    if (P <= 0) return;
+    mark_visible_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, means3D, view, present);
+}
+
+// ---- SH -> RGB, reference forward.cu:20-79. `c` holds the (DEG+1)^2 * 3 coefficients of this Gaussian.
+template <int DEG>
+__device__ __forceinline__ void sh_to_rgb(const float* c, float x, float y, float z, float out[3])
+{
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        float res = SH_C0 * c[0 * 3 + ch];
+        if (DEG > 0) {
+            res = res - SH_C1 * y * c[1 * 3 + ch] + SH_C1 * z * c[2 * 3 + ch] - SH_C1 * x * c[3 * 3 + ch];
+            if (DEG > 1) {
+                float xx = x * x, yy = y * y, zz = z * z;
+                float xy = x * y, yz = y * z, xz = x * z;
+                res = res + SH_C2_0 * xy * c[4 * 3 + ch] + SH_C2_1 * yz * c[5 * 3 + ch] +
+                      SH_C2_2 * (2.0f * zz - xx - yy) * c[6 * 3 + ch] + SH_C2_3 * xz * c[7 * 3 + ch] +
+                      SH_C2_4 * (xx - yy) * c[8 * 3 + ch];
+                if (DEG > 2) {
+                    res = res + SH_C3_0 * y * (3.0f * xx - yy) * c[9 * 3 + ch] + SH_C3_1 * xy * z * c[10 * 3 + ch] +
+                          SH_C3_2 * y * (4.0f * zz - xx - yy) * c[11 * 3 + ch] +
+                          SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * c[12 * 3 + ch] +
+                          SH_C3_4 * x * (4.0f * zz - xx - yy) * c[13 * 3 + ch] + SH_C3_5 * z * (xx - yy) * c[14 * 3 + ch] +
+                          SH_C3_6 * x * (xx - 3.0f * yy) * c[15 * 3 + ch];
+                }
+            }
+        }
+        out[ch] = res + 0.5f;
+    }
+}
+
+struct PreArgs {
+    int P, M, W, H, gx, gy;
+    const float* means3D; const float* sh; const float* colors_precomp; const float* opacities;
+    const float* scales; const float* scale_factors; const float* rotations; const float* cov3D_precomp;
+    const int64_t* sh_indices; const int64_t* g_indices;
+    const float* view; const float* proj; const float* campos;
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+    int prefiltered, clamp_color;
+    int32_t* radii; float4* splat; float* depths; uint32_t* tiles_touched; uint16_t* rects; uint8_t* clamped;
+};
+
+template <int DEG>
+__global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.P) return;
+
+    int32_t out_radius = 0;
+    uint32_t out_tiles = 0;
+    do {
+        const f3 p = { a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2] };
+        const f3 p_view = xform4x3(p, a.view);
+        if (!a.prefiltered && p_view.z <= 0.01f) break;           // auxiliary.h:156
+
+        const float4 p_hom = xform4x4(p, a.proj);
+        const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+        const float projx = p_hom.x * p_w, projy = p_hom.y * p_w;
+
+        float cov3D[6];
+        if (a.cov3D_precomp) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) cov3D[q] = a.cov3D_precomp[6 * (size_t)i + q];
+        } else if (a.g_indices) {                                  // forward_indexed.cu:223
+            const size_t g = (size_t)a.g_indices[i];
+            const float4 rot = *reinterpret_cast<const float4*>(a.rotations + 4 * g);
+            cov3d_from_scale_rot(a.scales[3 * g], a.scales[3 * g + 1], a.scales[3 * g + 2],
+                                 a.scale_factors[i] * a.scale_modifier, rot, cov3D);
+        } else {                                                   // forward.cu:220
+            const float4 rot = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)i);
+            cov3d_from_scale_rot(a.scales[3 * (size_t)i], a.scales[3 * (size_t)i + 1], a.scales[3 * (size_t)i + 2],
+                                 a.scale_modifier, rot, cov3D);
+        }
+        const Cov2D cv = cov2d(p, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.view);
+
+        const float det = (cv.a * cv.c - cv.b * cv.b);             // forward.cu:228-232
+        if (det == 0.0f) break;
+        const float det_inv = 1.f / det;
+        const float conic_a = cv.c * det_inv, conic_b = -cv.b * det_inv, conic_c = cv.a * det_inv;
+
+        const float mid = 0.5f * (cv.a + cv.c);                    // forward.cu:238-246
+        const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        const float pix = ndc2pix(projx, a.W), piy = ndc2pix(projy, a.H);
+        int x0, y0, x1, y1;
+        get_rect(pix, piy, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
+        if ((x1 - x0) * (y1 - y0) == 0) break;
+
+        float rgb[3];
+        uint8_t clamp_bits = 0;
+        if (a.colors_precomp) {
+            rgb[0] = a.colors_precomp[3 * (size_t)i];
+            rgb[1] = a.colors_precomp[3 * (size_t)i + 1];
+            rgb[2] = a.colors_precomp[3 * (size_t)i + 2];
+        } else {                                                   // forward.cu:20-79
+            const size_t row = a.sh_indices ? (size_t)a.sh_indices[i] : (size_t)i;
+            const float* shp = a.sh + row * (size_t)a.M * 3;
+            constexpr int NC = (DEG + 1) * (DEG + 1) * 3;
+            float c[NC];
+            if ((a.M * 3) % 4 == 0 && NC % 4 == 0) {               // 16-byte aligned rows: M = 4, 16
+#pragma unroll
+                for (int q = 0; q < NC / 4; q++) {
+                    const float4 v = reinterpret_cast<const float4*>(shp)[q];
+                    c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NC; q++) c[q] = shp[q];
+            }
+            f3 dir = { p.x - a.campos[0], p.y - a.campos[1], p.z - a.campos[2] };
+            const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+            dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
+            sh_to_rgb<DEG>(c, dir.x, dir.y, dir.z, rgb);
+            if (a.clamp_color) {                                   // forward.cu:65-72
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    if (rgb[ch] < 0) clamp_bits |= (uint8_t)(1u << ch);
+                    rgb[ch] = fmaxf(rgb[ch], 0.0f);
+                }
+            }
+        }
+
+        out_radius = (int32_t)my_radius;
+        out_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
+        a.depths[i] = p_view.z;
+        a.clamped[i] = clamp_bits;
+        uint16_t* rc = a.rects + 4 * (size_t)i;
+        rc[0] = (uint16_t)x0; rc[1] = (uint16_t)y0; rc[2] = (uint16_t)x1; rc[3] = (uint16_t)y1;
+        float4* rec = a.splat + 3 * (size_t)i;
+        rec[0] = make_float4(pix, piy, conic_a, conic_b);
+        rec[1] = make_float4(conic_c, a.opacities[i], rgb[0], rgb[1]);
+        rec[2] = make_float4(rgb[2], 0.f, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
+                             __uint_as_float((uint32_t)x1 | ((uint32_t)y1 << 16)));
+    } while (false);
+
+    a.radii[i] = out_radius;
+    a.tiles_touched[i] = out_tiles;
+}
+
+void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, hipStream_t s)
+{
+    if (p.P <= 0) return;
+    PreArgs a;
+    a.P = p.P; a.M = p.M; a.W = p.W; a.H = p.H; a.gx = tiles_x(p.W); a.gy = tiles_y(p.H);
+    a.means3D = p.means3D; a.sh = p.sh; a.colors_precomp = p.colors_precomp; a.opacities = p.opacities;
+    a.scales = p.scales; a.scale_factors = p.scale_factors; a.rotations = p.rotations; a.cov3D_precomp = p.cov3D_precomp;
+    a.sh_indices = p.sh_indices; a.g_indices = p.g_indices;
+    a.view = p.viewmatrix; a.proj = p.projmatrix; a.campos = p.campos;
+    a.tan_fovx = p.tan_fovx; a.tan_fovy = p.tan_fovy;
+    a.focal_y = p.H / (2.0f * p.tan_fovy);                       // rasterizer_impl.cu:219-220
+    a.focal_x = p.W / (2.0f * p.tan_fovx);
+    a.scale_modifier = p.scale_modifier; a.prefiltered = p.prefiltered; a.clamp_color = p.clamp_color;
+    a.radii = radii; a.splat = g.splat; a.depths = g.depths; a.tiles_touched = g.tiles_touched; a.rects = g.rects;
+    a.clamped = g.clamped;
+    const dim3 grid((p.P + 255) / 256), block(256);
+    const int deg = p.colors_precomp ? 0 : p.D;
+    switch (deg) {
+        case 0: preprocess_kernel<0><<<grid, block, 0, s>>>(a); break;
+        case 1: preprocess_kernel<1><<<grid, block, 0, s>>>(a); break;
+        case 2: preprocess_kernel<2><<<grid, block, 0, s>>>(a); break;
+        default: preprocess_kernel<3><<<grid, block, 0, s>>>(a); break;
+    }
+}
+
+// ---- K5: one (key, value) pair per Gaussian x tile, reference rasterizer_impl.cu:70-111.
+// Also stamps the exclusive instance offset into the splat record (word 9).
+__global__ void __launch_bounds__(256)
+duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ offsets,
+                           const uint16_t* __restrict__ rects, const float* __restrict__ depths, float4* __restrict__ splat,
+                           uint64_t* __restrict__ keys, uint32_t* __restrict__ values, int grid_x)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    if (tiles_touched[i] == 0) return;           // == reference's radii[idx] > 0
+    uint32_t off = (i == 0) ? 0u : offsets[i - 1];
+    reinterpret_cast<float*>(splat + 3 * (size_t)i + 2)[1] = __uint_as_float(off);
+    const uint2 rc = *reinterpret_cast<const uint2*>(rects + 4 * (size_t)i);
+    const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
+    const uint64_t dbits = (uint64_t)__float_as_uint(depths[i]);
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            uint64_t key = (uint64_t)(uint32_t)(y * grid_x + x);
+            key <<= 32;
+            key |= dbits;
+            keys[off] = key;
+            values[off] = (uint32_t)i;
+            off++;
+        }
+}
+
+void launch_duplicate_with_keys(int P, const GeomPtrs& g, const int32_t* /*radii*/, const BinPtrs& b, int grid_x, hipStream_t s)
+{
+    if (P <= 0) return;
+    duplicate_with_keys_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.tiles_touched, g.point_offsets, g.rects, g.depths,
+                                                               g.splat, b.keys_unsorted, b.values_unsorted, grid_x);
+}
+
+// ---- K8: reference rasterizer_impl.cu:116-138 (ranges pre-zeroed by the caller, :308)
+__global__ void __launch_bounds__(256)
+identify_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L) return;
+    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0) ranges[cur].x = 0;
+    else {
+        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        if (cur != prev) {
+            ranges[prev].y = (uint32_t)idx;
+            ranges[cur].x = (uint32_t)idx;
+        }
+    }
+    if (idx == L - 1) ranges[cur].y = (uint32_t)L;
+}
+
+void launch_identify_ranges(int R, const uint64_t* keys_sorted, uint2* ranges, hipStream_t s)
+{
+    if (R <= 0) return;
+    identify_ranges_kernel<<<(R + 255) / 256, 256, 0, s>>>(R, keys_sorted, ranges);
+}
+
+} // namespace c3dgs

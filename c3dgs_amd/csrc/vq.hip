@@ -1,0 +1,216 @@
+// vq.hip -- nearest-codeword search and the weighted EMA k-means update for gfx950.
+//
+//   K14  weighted_distance   reference submodules/weighted_distance/weighted_distance.cu:9-58
+//   V3   vq_accumulate/apply reference compression/vq.py:28-35,45-46,73-77
+//
+// weighted_distance keeps the reference's exact semantics: per (point, codeword) a k-ordered fp32
+// chain r = fma(d, d, r) with d = x_k - c_k, strict '<' so the lowest index wins ties. The reference
+// launches 32-thread blocks with one thread per point and re-reads the whole codebook from global
+// memory per thread; here a 256-thread workgroup keeps its points in registers (2 per lane) and
+// streams the codebook through LDS in tiles that every lane reads as a broadcast.
+#include "common.hpp"
+#include <cfloat>
+
+namespace c3dgs {
+
+constexpr int WD_BLOCK = 256;
+constexpr int WD_PPT = 2;        // points per thread
+
+template <int K> struct RowVec { };
+template <> struct RowVec<48> { using type = float4; static constexpr int N = 4; };
+template <> struct RowVec<12> { using type = float4; static constexpr int N = 4; };
+template <> struct RowVec<6>  { using type = float2; static constexpr int N = 2; };
+
+template <int K, int CT>
+__global__ void __launch_bounds__(WD_BLOCK)
+weighted_distance_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather,
+                         const float* __restrict__ codebook, float* __restrict__ out_dist, int64_t* __restrict__ out_idx)
+{
+    using V = typename RowVec<K>::type;
+    constexpr int VN = RowVec<K>::N;
+    constexpr int KV = K / VN;
+    __shared__ V s_cb[CT * KV];
+
+    const int tid = threadIdx.x;
+    float x[WD_PPT][K];
+    int64_t n[WD_PPT];
+    float best[WD_PPT];
+    int besti[WD_PPT];
+#pragma unroll
+    for (int p = 0; p < WD_PPT; p++) {
+        n[p] = ((int64_t)blockIdx.x * WD_PPT + p) * WD_BLOCK + tid;
+        best[p] = FLT_MAX;
+        besti[p] = 0;
+        const int64_t row = n[p] < N ? (gather ? gather[n[p]] : n[p]) : 0;
+        const V* src = reinterpret_cast<const V*>(coefs + row * K);
+#pragma unroll
+        for (int q = 0; q < KV; q++) {
+            const V v = (N > 0) ? src[q] : V{};
+            const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+            for (int e = 0; e < VN; e++) x[p][q * VN + e] = f[e];
+        }
+    }
+    for (int c0 = 0; c0 < C; c0 += CT) {
+        const int ct = min(CT, C - c0);
+        __syncthreads();
+        const V* gsrc = reinterpret_cast<const V*>(codebook + (size_t)c0 * K);
+        for (int q = tid; q < ct * KV; q += WD_BLOCK) s_cb[q] = gsrc[q];
+        __syncthreads();
+        for (int c = 0; c < ct; c++) {
+            float r[WD_PPT];
+#pragma unroll
+            for (int p = 0; p < WD_PPT; p++) r[p] = 0.f;
+#pragma unroll
+            for (int q = 0; q < KV; q++) {
+                const V v = s_cb[c * KV + q];
+                const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+                for (int e = 0; e < VN; e++)
+#pragma unroll
+                    for (int p = 0; p < WD_PPT; p++) {
+                        const float d = x[p][q * VN + e] - f[e];
+                        r[p] = fmaf(d, d, r[p]);
+                    }
+            }
+#pragma unroll
+            for (int p = 0; p < WD_PPT; p++)
+                if (r[p] < best[p]) { best[p] = r[p]; besti[p] = c0 + c; }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < WD_PPT; p++)
+        if (n[p] < N) { out_dist[n[p]] = best[p]; out_idx[n[p]] = (int64_t)besti[p]; }
+}
+
+// any K: one thread per point, codebook tile in LDS, point row re-read from global/L1.
+template <int CT_FLOATS>
+__global__ void __launch_bounds__(WD_BLOCK)
+weighted_distance_generic_kernel(int64_t N, int C, int K, const float* __restrict__ coefs, const int64_t* __restrict__ gather,
+                                 const float* __restrict__ codebook, float* __restrict__ out_dist, int64_t* __restrict__ out_idx)
+{
+    __shared__ float s_cb[CT_FLOATS];
+    const int tid = threadIdx.x;
+    const int64_t n = (int64_t)blockIdx.x * WD_BLOCK + tid;
+    const int CT = max(1, CT_FLOATS / K);
+    const int64_t row = n < N ? (gather ? gather[n] : n) : 0;
+    const float* xr = coefs + row * K;
+    float best = FLT_MAX;
+    int besti = 0;
+    for (int c0 = 0; c0 < C; c0 += CT) {
+        const int ct = min(CT, C - c0);
+        __syncthreads();
+        for (int q = tid; q < ct * K; q += WD_BLOCK) s_cb[q] = codebook[(size_t)c0 * K + q];
+        __syncthreads();
+        if (n < N)
+            for (int c = 0; c < ct; c++) {
+                float r = 0.f;
+                for (int k = 0; k < K; k++) {
+                    const float d = xr[k] - s_cb[c * K + k];
+                    r = fmaf(d, d, r);
+                }
+                if (r < best) { best = r; besti = c0 + c; }
+            }
+    }
+    if (n < N) { out_dist[n] = best; out_idx[n] = (int64_t)besti; }
+}
+
+int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const int64_t* gather, const float* codebook,
+                             float* out_dist, int64_t* out_idx, hipStream_t s)
+{
+    if (N <= 0) return 0;
+    const int64_t per_block = (int64_t)WD_BLOCK * WD_PPT;
+    const unsigned grid = (unsigned)((N + per_block - 1) / per_block);
+    const bool al16 = (((uintptr_t)coefs | (uintptr_t)codebook) & 15) == 0;
+    const bool al8 = (((uintptr_t)coefs | (uintptr_t)codebook) & 7) == 0;
+    if (K == 48 && al16) weighted_distance_kernel<48, 128><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
+    else if (K == 12 && al16) weighted_distance_kernel<12, 512><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
+    else if (K == 6 && al8) weighted_distance_kernel<6, 1024><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
+    else {
+        if (K > 6144) return 1;
+        const unsigned g2 = (unsigned)((N + WD_BLOCK - 1) / WD_BLOCK);
+        weighted_distance_generic_kernel<6144><<<g2, WD_BLOCK, 0, s>>>(N, C, K, coefs, gather, codebook, out_dist, out_idx);
+    }
+    return 0;
+}
+
+// ---- VectorQuantize.update, part 1: weighted scatter-sums (compression/vq.py:31,33) into S[K, D+1].
+// Element e = n*(D+1)+c so that the D+1 atomics of one point are contiguous (one ~200-byte run per
+// point for D=48: the access shape the chip's memory-side float atomics run fastest on).
+__global__ void __launch_bounds__(256)
+vq_accumulate_kernel(int64_t B, int D, const float* __restrict__ x, const float* __restrict__ w,
+                     const int64_t* __restrict__ gather, const int64_t* __restrict__ idx, float* __restrict__ S)
+{
+    const int D1 = D + 1;
+    const int64_t total = B * D1;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t n = e / D1;
+        const int c = (int)(e - n * D1);
+        const int64_t row = gather ? gather[n] : n;
+        const float wn = w[row];
+        const float v = (c < D) ? x[row * D + c] * wn : wn;
+        atomicAdd(S + idx[n] * D1 + c, v);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+vq_dist_sum_kernel(int64_t B, const float* __restrict__ dist, double* __restrict__ out)
+{
+    __shared__ double s_red[256];
+    double acc = 0.0;
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < B; n += (int64_t)gridDim.x * 256) acc += (double)dist[n];
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, s_red[0]);
+}
+
+void launch_vq_accumulate(int64_t B, int K, int D, const float* x, const float* w, const int64_t* gather,
+                          const int64_t* idx, const float* dist, float* S, double* dist_sum, hipStream_t s)
+{
+    (void)K;
+    if (B <= 0) return;
+    const int64_t total = B * (D + 1);
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    vq_accumulate_kernel<<<grid, 256, 0, s>>>(B, D, x, w, gather, idx, S);
+    if (dist && dist_sum) {
+        const unsigned g2 = (unsigned)std::min<int64_t>((B + 255) / 256, 1024);
+        vq_dist_sum_kernel<<<g2, 256, 0, s>>>(B, dist, dist_sum);
+    }
+}
+
+// ---- part 2: EMA + optional trace normalisation; one thread per codeword row. Every operation is
+// a single rounded fp32 op (__fmul_rn/__fadd_rn/__fdiv_rn) in the order torch evaluates
+// moving_avg.mul_(decay).add_(new, alpha) so all ranks of a sharded run stay bit-identical.
+__global__ void __launch_bounds__(256)
+vq_apply_kernel(int K, int D, const float* __restrict__ S, float* __restrict__ codebook, float* __restrict__ entry_importance,
+                float decay, float alpha, float eps, int scale_normalize)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const float* srow = S + (size_t)k * (D + 1);
+    float* cb = codebook + (size_t)k * D;
+    const float aw = srow[D];
+    entry_importance[k] = __fadd_rn(__fmul_rn(entry_importance[k], decay), __fmul_rn(alpha, aw));
+    const float den = __fadd_rn(aw, eps);
+    for (int d = 0; d < D; d++) {
+        const float nw = __fdiv_rn(srow[d], den);
+        cb[d] = __fadd_rn(__fmul_rn(cb[d], decay), __fmul_rn(alpha, nw));
+    }
+    if (scale_normalize && D >= 6) {
+        const float tr = __fadd_rn(__fadd_rn(cb[0], cb[3]), cb[5]);
+        for (int d = 0; d < D; d++) cb[d] = __fdiv_rn(cb[d], tr);
+    }
+}
+
+void launch_vq_apply(int K, int D, const float* S, float* codebook, float* entry_importance, float decay, float alpha,
+                     float eps, int scale_normalize, hipStream_t s)
+{
+    if (K <= 0) return;
+    vq_apply_kernel<<<(K + 255) / 256, 256, 0, s>>>(K, D, S, codebook, entry_importance, decay, alpha, eps, scale_normalize);
+}
+
+} // namespace c3dgs

@@ -1,0 +1,311 @@
+"""Host-side mirror of the reference's VQ path on top of the MI355X C-ABI library:
+
+    weightedDistance          <- weighted_distance._C.weightedDistance (submodules/weighted_distance/ext.cpp:5)
+    VectorQuantize, ema_inplace, vq_features, join_features, CompressionSettings,
+    compress_color, compress_covariance, compress_gaussians   <- compression/vq.py:15-223
+
+Same names, argument meaning and error behaviour.  Additions (new functionality, BASELINE.json north_star):
+  * `vq_features(..., group=...)`: every rank of a torch.distributed group draws the SAME batch, assigns its
+    contiguous slice, and the per-cluster partial sums S[K, D+1] (sum w*x | sum w) plus the distance sum are
+    all-reduced (RCCL over xGMI when the backend is "nccl") once per Lloyd step; every rank then applies
+    the identical EMA update, so codebooks stay bit-identical across ranks.
+  * `batches=` / `init_rand=`: the two RNG draws can be passed in as data (parity tests, sharded runs).
+There is no CPU path: tensors must live on the GPU and libc3dgs_hip.so must be present.
+"""
+import ctypes as C
+import gc
+import time
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def weightedDistance(coefs: torch.Tensor, codebook: torch.Tensor, gather: Optional[torch.Tensor] = None):
+    """(min squared distance f32[N], argmin i64[N]); reference weighted_distance.cu:60-93.
+    `gather` (int64[N], optional) makes row n of the query `coefs[gather[n]]` without materialising it."""
+    if coefs.dim() != 2 or codebook.dim() != 2:
+        raise RuntimeError("ceofs and codebook must have dimension 2")          # weighted_distance.cu:64-67
+    if codebook.size(1) != coefs.size(1):
+        raise RuntimeError("coefs and codebook must have same number of channels")  # :69-72
+    if not coefs.is_cuda or not codebook.is_cuda:
+        raise RuntimeError("c3dgs_amd: weightedDistance needs GPU tensors (there is no CPU path)")
+    L = _lib.lib()
+    x = coefs.detach().contiguous().float()
+    cb = codebook.detach().contiguous().float()
+    if gather is not None:
+        gather = gather.to(device=x.device, dtype=torch.int64).contiguous()
+    N = int(gather.numel()) if gather is not None else int(x.size(0))
+    dist = torch.zeros(N, dtype=torch.float32, device=x.device)
+    idx = torch.zeros(N, dtype=torch.int64, device=x.device)
+    if N > 0 and cb.size(0) > 0:
+        with torch.cuda.device(x.device):
+            rc = L.c3dgs_weighted_distance(N, int(cb.size(0)), int(x.size(1)), x.data_ptr(),
+                                           gather.data_ptr() if gather is not None else None, cb.data_ptr(),
+                                           dist.data_ptr(), idx.data_ptr(), _stream(x.device))
+        _lib.check(rc)
+    return dist, idx
+
+
+def ema_inplace(moving_avg: torch.Tensor, new: torch.Tensor, decay: float):
+    """compression/vq.py:45-46."""
+    moving_avg.data.mul_(decay).add_(new, alpha=(1 - decay))
+
+
+class HipOps:
+    """The three device operations of the VQ path, bound to libc3dgs_hip.so. (Tests of the sharding control
+    flow may inject another object with the same three methods; the package itself only ever uses this one.)"""
+
+    @staticmethod
+    def assign(x, codebook, gather=None):
+        return weightedDistance(x, codebook, gather)
+
+    @staticmethod
+    def accumulate(x, importance, gather, idx, min_dists, K):
+        """S f32[K, D+1] = [sum w*x | sum w] over the rows selected by `gather`, and sum(min_dists) as f64[1]."""
+        L = _lib.lib()
+        D = int(x.size(1))
+        S = torch.zeros(K, D + 1, dtype=torch.float32, device=x.device)
+        dsum = torch.zeros(1, dtype=torch.float64, device=x.device)
+        B = int(idx.numel())
+        if B > 0:
+            xw = x.detach().contiguous().float()
+            w = importance.detach().contiguous().float()
+            with torch.cuda.device(x.device):
+                rc = L.c3dgs_vq_accumulate(B, K, D, xw.data_ptr(), w.data_ptr(),
+                                           gather.data_ptr() if gather is not None else None, idx.data_ptr(),
+                                           min_dists.data_ptr(), S.data_ptr(), dsum.data_ptr(), _stream(x.device))
+            _lib.check(rc)
+        return S, dsum
+
+    @staticmethod
+    def apply(S, codebook, entry_importance, decay, eps, scale_normalize):
+        L = _lib.lib()
+        K, D = codebook.shape
+        assert codebook.is_contiguous() and entry_importance.is_contiguous() and codebook.dtype == torch.float32
+        with torch.cuda.device(codebook.device):
+            rc = L.c3dgs_vq_apply(K, D, S.data_ptr(), codebook.data_ptr(), entry_importance.data_ptr(), float(decay),
+                                  float(1 - decay), float(eps), int(bool(scale_normalize)), _stream(codebook.device))
+        _lib.check(rc)
+
+
+class VectorQuantize(nn.Module):
+    """compression/vq.py:15-42."""
+
+    def __init__(self, channels: int, codebook_size: int = 2 ** 12, decay: float = 0.5, ops=None) -> None:
+        super().__init__()
+        self.decay = decay
+        self.codebook = nn.Parameter(torch.empty(codebook_size, channels), requires_grad=False)
+        nn.init.kaiming_uniform_(self.codebook)
+        self.entry_importance = nn.Parameter(torch.zeros(codebook_size), requires_grad=False)
+        self.eps = 1e-5
+        self.ops = HipOps if ops is None else ops
+
+    def uniform_init(self, x: torch.Tensor, rand: Optional[torch.Tensor] = None):
+        amin, amax = x.aminmax()
+        r = torch.rand_like(self.codebook) if rand is None else rand.to(self.codebook)
+        self.codebook.data = r * (amax - amin) + amin
+
+    def partial_sums(self, x: torch.Tensor, importance: torch.Tensor, gather: Optional[torch.Tensor] = None):
+        """Assignment + weighted scatter-sums of one (slice of a) batch.
+        Returns (min_dists f32[B], S f32[K, D+1] = [sum w*x | sum w], dist_sum f64[1])."""
+        min_dists, idx = self.ops.assign(x, self.codebook.data, gather)
+        S, dsum = self.ops.accumulate(x, importance, gather, idx, min_dists, int(self.codebook.shape[0]))
+        return min_dists, S, dsum
+
+    def apply_sums(self, S: torch.Tensor, scale_normalize: bool = False):
+        """EMA update from (all-reduced) sums; vq.py:32,34 (+ :73-77 when scale_normalize)."""
+        self.ops.apply(S, self.codebook.data, self.entry_importance.data, self.decay, self.eps, scale_normalize)
+
+    def update(self, x: torch.Tensor, importance: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            min_dists, S, _ = self.partial_sums(x, importance)
+            self.apply_sums(S)
+            return min_dists
+
+    def forward(self, x: torch.Tensor, return_dists: bool = False):
+        min_dists, idx = self.ops.assign(x.detach(), self.codebook.detach())
+        if return_dists:
+            return self.codebook[idx], idx, min_dists
+        return self.codebook[idx], idx
+
+
+def _dist_info(group):
+    import torch.distributed as dist
+    if group is None or not dist.is_available() or not dist.is_initialized():
+        return None, 0, 1
+    g = None if group is True else group
+    return dist, dist.get_rank(g), dist.get_world_size(g)
+
+
+def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size: int, vq_chunk: int = 2 ** 16,
+                steps: int = 1000, decay: float = 0.8, scale_normalize: bool = False, silent: bool = False,
+                group=None, batches=None, init_rand: Optional[torch.Tensor] = None, return_errors: bool = False,
+                shard_final: bool = True, ops=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """compression/vq.py:49-87.  group=None: single GPU.  group=True (default process group) or a
+    ProcessGroup: sharded Lloyd steps with one all-reduce of S[K, D+1] per step.
+    The per-step `.item()` host sync of the reference (vq.py:71) is deferred to the end."""
+    dist, rank, world = _dist_info(group)
+    pg = None if group is True else group
+    dev = features.device
+    N = features.shape[0]
+    importance_n = importance / importance.max()
+    vq_model = VectorQuantize(channels=features.shape[-1], codebook_size=codebook_size, decay=decay, ops=ops).to(device=dev)
+    if init_rand is None and world > 1:
+        init_rand = torch.rand(codebook_size, features.shape[-1], device=dev)
+        dist.broadcast(init_rand, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
+    vq_model.uniform_init(features, init_rand)
+
+    feats = features.detach().contiguous().float()
+    imp = importance_n.detach().contiguous().float()
+    err_sums = []
+    it = range(steps) if batches is None else range(len(batches))
+    for s in it:
+        if batches is not None:
+            batch = batches[s].to(device=dev, dtype=torch.int64)
+        else:
+            batch = torch.randint(low=0, high=N, size=[vq_chunk])                   # CPU RNG, as vq.py:69
+            if world > 1:                                                           # every rank uses rank 0's draw
+                batch = batch.to(dev)
+                dist.broadcast(batch, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
+            batch = batch.to(dev)
+        B = int(batch.numel())
+        lo, hi = (rank * B) // world, ((rank + 1) * B) // world
+        with torch.no_grad():
+            _, S, dsum = vq_model.partial_sums(feats, imp, gather=batch[lo:hi].contiguous())
+            if world > 1:
+                dist.all_reduce(S, group=pg)
+                dist.all_reduce(dsum, group=pg)
+            vq_model.apply_sums(S, scale_normalize=scale_normalize)
+        err_sums.append((dsum, B))
+    gc.collect()
+
+    start = time.time()
+    if world > 1 and shard_final:
+        lo, hi = (rank * N) // world, ((rank + 1) * N) // world
+        _, local = vq_model.ops.assign(feats[lo:hi], vq_model.codebook.data)
+        sizes = [((r + 1) * N) // world - (r * N) // world for r in range(world)]
+        parts = [torch.empty(sz, dtype=torch.int64, device=dev) for sz in sizes]
+        dist.all_gather(parts, local, group=pg)
+        vq_indices = torch.cat(parts, 0)
+    else:
+        _, vq_indices = vq_model(feats)
+    if vq_indices.is_cuda:
+        torch.cuda.synchronize(device=vq_indices.device)
+    end = time.time()
+    if not silent:
+        print(f"calculating indices took {end - start} seconds ")
+    if return_errors:
+        errors = [float(d.item()) / max(b, 1) for d, b in err_sums]
+        return vq_model.codebook.data.detach(), vq_indices.detach(), errors
+    return vq_model.codebook.data.detach(), vq_indices.detach()
+
+
+def join_features(all_features: torch.Tensor, keep_mask: torch.Tensor, codebook: torch.Tensor,
+                  codebook_indices: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """compression/vq.py:90-103."""
+    keep_features = all_features[keep_mask]
+    compressed_features = torch.cat([codebook, keep_features], 0)
+    indices = torch.zeros(len(all_features), dtype=torch.long, device=all_features.device)
+    indices[~keep_mask] = codebook_indices
+    indices[keep_mask] = torch.arange(len(keep_features), device=indices.device) + len(codebook)
+    return compressed_features, indices
+
+
+@dataclass
+class CompressionSettings:
+    """compression/vq.py:106-114."""
+    codebook_size: int
+    importance_prune: float
+    importance_include: float
+    importance_include_relative: float
+    steps: int
+    decay: float
+    batch_size: int
+
+
+def compress_color(gaussians, color_importance: torch.Tensor, color_comp: CompressionSettings,
+                   color_compress_non_dir: bool, silent: bool, group=None):
+    """compression/vq.py:117-147 (`gaussians` is duck-typed: get_features, set_color_indexed)."""
+    keep_mask = color_importance > color_comp.importance_include
+    if not silent:
+        print(f"color keep: {keep_mask.float().mean() * 100:.2f}%")
+    vq_mask_c = ~keep_mask
+    if color_compress_non_dir:
+        n_sh_coefs = gaussians.get_features.shape[1]
+        color_features = gaussians.get_features.detach().flatten(-2)
+    else:
+        n_sh_coefs = gaussians.get_features.shape[1] - 1
+        color_features = gaussians.get_features[:, 1:].detach().flatten(-2)
+    if vq_mask_c.any():
+        if not silent:
+            print("compressing color...")
+        color_codebook, color_vq_indices = vq_features(color_features[vq_mask_c], color_importance[vq_mask_c],
+                                                       color_comp.codebook_size, color_comp.batch_size, color_comp.steps,
+                                                       silent=silent, group=group)
+    else:
+        color_codebook = torch.empty((0, color_features.shape[-1]), device=color_features.device)
+        color_vq_indices = torch.empty((0,), device=color_features.device, dtype=torch.long)
+    compressed_features, indices = join_features(color_features, keep_mask, color_codebook, color_vq_indices)
+    gaussians.set_color_indexed(compressed_features.reshape(-1, n_sh_coefs, 3), indices)
+
+
+def compress_covariance(gaussians, gaussian_importance: torch.Tensor, gaussian_comp: CompressionSettings, silent: bool,
+                        group=None, extract_rot_scale=None, to_full_cov=None):
+    """compression/vq.py:149-191. The eigendecomposition helpers (utils/splats.py:7-35) are host-model code
+    outside the hot path; pass them in (the reference's own functions work unchanged)."""
+    keep_mask_g = gaussian_importance > gaussian_comp.importance_include
+    vq_mask_g = ~keep_mask_g
+    if not silent:
+        print(f"gaussians keep: {keep_mask_g.float().mean() * 100:.2f}%")
+    covariance = gaussians.get_normalized_covariance(strip_sym=True).detach()
+    if vq_mask_g.any():
+        if not silent:
+            print("compressing gaussian splats...")
+        cov_codebook, cov_vq_indices = vq_features(covariance[vq_mask_g], gaussian_importance[vq_mask_g],
+                                                   gaussian_comp.codebook_size, gaussian_comp.batch_size,
+                                                   gaussian_comp.steps, scale_normalize=True, silent=silent, group=group)
+    else:
+        cov_codebook = torch.empty((0, covariance.shape[1]), device=covariance.device)
+        cov_vq_indices = torch.empty((0,), device=covariance.device, dtype=torch.long)
+    compressed_cov, cov_indices = join_features(covariance, keep_mask_g, cov_codebook, cov_vq_indices)
+    if extract_rot_scale is None or to_full_cov is None:
+        raise RuntimeError("compress_covariance needs extract_rot_scale and to_full_cov (reference utils/splats.py)")
+    rot_vq, scale_vq = extract_rot_scale(to_full_cov(compressed_cov))
+    gaussians.set_gaussian_indexed(rot_vq.to(compressed_cov.device), scale_vq.to(compressed_cov.device), cov_indices)
+
+
+def compress_gaussians(gaussians, color_importance: torch.Tensor, gaussian_importance: torch.Tensor,
+                       color_comp: Optional[CompressionSettings], gaussian_comp: Optional[CompressionSettings],
+                       color_compress_non_dir: bool, prune_threshold: float = 0., silent: bool = False, group=None,
+                       extract_rot_scale=None, to_full_cov=None):
+    """compression/vq.py:194-223."""
+    with torch.no_grad():
+        if prune_threshold >= 0:
+            non_prune_mask = color_importance > prune_threshold
+            if not silent:
+                print(f"prune: {(1 - non_prune_mask.float().mean()) * 100:.2f}%")
+            gaussians.mask_splats(non_prune_mask)
+            gaussian_importance = gaussian_importance[non_prune_mask]
+            color_importance = color_importance[non_prune_mask]
+        if color_comp.importance_include is None:
+            color_comp.importance_include = torch.quantile(color_importance, color_comp.importance_include_relative).item()
+            if not silent:
+                print(f"Setting color threshold to {color_comp.importance_include}")
+        if gaussian_comp.importance_include is None:
+            gaussian_comp.importance_include = torch.quantile(gaussian_importance,
+                                                              gaussian_comp.importance_include_relative).item()
+            if not silent:
+                print(f"Setting gaussian threshold to {gaussian_comp.importance_include}")
+        if color_comp is not None:
+            compress_color(gaussians, color_importance, color_comp, color_compress_non_dir, silent=silent, group=group)
+        if gaussian_comp is not None:
+            compress_covariance(gaussians, gaussian_importance, gaussian_comp, silent=silent, group=group,
+                                extract_rot_scale=extract_rot_scale, to_full_cov=to_full_cov)

@@ -1,0 +1,187 @@
+/*
+ * c3dgs_hip.h -- C ABI of libc3dgs_hip.so: the MI355X (gfx950) rasterizer + VQ hot path.
+ *
+ * This is the drop-in boundary for the reference's two native extensions
+ *   diff_gaussian_rasterization*._C   (submodules/diff-gaussian-rasterization/ext.cpp:15-21,
+ *                                      signatures rasterize_points.h:18-122)
+ *   weighted_distance._C              (submodules/weighted_distance/ext.cpp:4-6)
+ * restated with plain pointers and sizes: no torch types, no C++ types, no CUDA/HIP types.
+ * Every pointer is a DEVICE pointer unless marked "host". `stream` is a hipStream_t passed as
+ * void* (NULL = the default stream). Every function returns 0 on success and a non-zero
+ * C3DGS_E_* code on failure; c3dgs_last_error() then returns a message (thread-local).
+ *
+ * "Empty tensor" semantics of the reference (torch.Tensor([]) -> data_ptr()==nullptr,
+ * forward.cu:214,250; backward.cu:390,394) are kept: an absent optional input is a NULL pointer.
+ */
+#ifndef C3DGS_HIP_H
+#define C3DGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C3DGS_ABI_VERSION 1
+
+enum {
+    C3DGS_OK = 0,
+    C3DGS_E_INVALID = 1, /* bad shape / missing or contradictory arguments (reference: AT_ERROR)   */
+    C3DGS_E_HIP = 2,     /* a HIP runtime or kernel error (reference: CHECK_CUDA under debug=True) */
+    C3DGS_E_ALLOC = 3    /* a resize callback returned NULL                                         */
+};
+
+/* Scratch buffers are owned by the caller and grown through a callback, exactly like the
+ * reference's std::function<char*(size_t)> resize lambdas (rasterize_points.cu:27-33,74-79;
+ * rasterizer.h:31-34). The callback must return a device pointer to at least `bytes` bytes,
+ * 256-byte aligned, that stays valid until the matching backward has run. */
+typedef void* (*c3dgs_resize_fn)(void* user, size_t bytes);
+
+/* Inputs shared by forward and backward (reference: the positional arguments of
+ * RasterizeGaussiansCUDA / RasterizeGaussiansIndexedCUDA, rasterize_points.cu:35-56,
+ * rasterize_points_indexed.cu:35-59). */
+typedef struct c3dgs_raster_params {
+    int32_t P;      /* Gaussians passed in                                                   */
+    int32_t D;      /* active SH degree (0..3)                                               */
+    int32_t M;      /* SH coefficients per row = sh.size(1); 0 when sh is absent             */
+    int32_t W, H;   /* image size                                                            */
+    int32_t SHS;    /* rows of the SH codebook   (indexed variant; else == P or 0)           */
+    int32_t GS;     /* rows of the scale/rotation codebooks (indexed variant; else == P or 0) */
+    const float* background;     /* [3]                                                      */
+    const float* means3D;        /* [P,3]                                                    */
+    const float* sh;             /* [P,M,3] | indexed: [SHS,M,3] | NULL                      */
+    const float* colors_precomp; /* [P,3] | NULL        (exactly one of sh / colors_precomp) */
+    const float* opacities;      /* [P]                                                      */
+    const float* scales;         /* [P,3] | indexed: [GS,3] | NULL                           */
+    const float* scale_factors;  /* indexed only: [P]                                        */
+    const float* rotations;      /* [P,4] | indexed: [GS,4] | NULL   (r,x,y,z), not normalised */
+    const float* cov3D_precomp;  /* [P,6] | NULL   (exactly one of scales+rotations / cov3D)  */
+    const int64_t* sh_indices;   /* indexed only: [P]                                        */
+    const int64_t* g_indices;    /* indexed only: [P]                                        */
+    const float* viewmatrix;     /* [16] world->camera, transposed (m[0],m[4],m[8],m[12] = row 0) */
+    const float* projmatrix;     /* [16] viewmatrix @ projection, same layout                */
+    const float* campos;         /* [3]                                                      */
+    float tan_fovx, tan_fovy;
+    float scale_modifier;
+    int32_t prefiltered;
+    int32_t clamp_color;
+    int32_t debug;               /* non-zero: synchronise and check after every stage        */
+} c3dgs_raster_params;
+
+/* Gradient outputs (reference: the tensors allocated in RasterizeGaussiansBackward*CUDA,
+ * rasterize_points.cu:153-162, rasterize_points_indexed.cu:166-176). The callee writes EVERY
+ * element of every non-NULL output (zeros for culled Gaussians), so the caller may pass
+ * uninitialised memory. A NULL pointer skips that output. */
+typedef struct c3dgs_raster_grads {
+    float* dL_dmeans2D;       /* [P,3]  (z component is always 0)                             */
+    float* dL_dcolors;        /* [P,3]                                                        */
+    float* dL_dopacity;       /* [P]                                                          */
+    float* dL_dmeans3D;       /* [P,3]                                                        */
+    float* dL_dcov3D;         /* [P,6]                                                        */
+    float* dL_dsh;            /* [P,M,3] | indexed: [SHS,M,3] (scatter-added)                 */
+    float* dL_dscales;        /* [P,3]   | indexed: [GS,3]    (scatter-added)                 */
+    float* dL_dscale_factors; /* indexed only: [P]                                            */
+    float* dL_drotations;     /* [P,4]   | indexed: [GS,4]    (scatter-added)                 */
+} c3dgs_raster_grads;
+
+/* ---- _C.mark_visible (rasterize_points.cu:202-221 -> rasterizer_impl.cu:54-66,141-149) ---- */
+int c3dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                       uint8_t* present /*[P] bool*/, void* stream);
+
+/* ---- _C.rasterize_gaussians (rasterize_points.cu:35-117 -> rasterizer_impl.cu:194-334) ----
+ * p->sh_indices, p->g_indices, p->scale_factors must be NULL.
+ * out_color [3,H,W] and radii [P] are fully written. *num_rendered (host) receives R. */
+int c3dgs_rasterize_gaussians(const c3dgs_raster_params* p,
+                              c3dgs_resize_fn geom_resize, void* geom_user,
+                              c3dgs_resize_fn binning_resize, void* binning_user,
+                              c3dgs_resize_fn image_resize, void* image_user,
+                              float* out_color, int32_t* radii, int32_t* num_rendered /*host*/, void* stream);
+
+/* ---- _C.rasterize_gaussians_indexed (rasterize_points_indexed.cu:35-123 -> rasterizer_impl.cu:440-586) */
+int c3dgs_rasterize_gaussians_indexed(const c3dgs_raster_params* p,
+                                      c3dgs_resize_fn geom_resize, void* geom_user,
+                                      c3dgs_resize_fn binning_resize, void* binning_user,
+                                      c3dgs_resize_fn image_resize, void* image_user,
+                                      float* out_color, int32_t* radii, int32_t* num_rendered /*host*/, void* stream);
+
+/* ---- _C.rasterize_gaussians_backward (rasterize_points.cu:119-200 -> rasterizer_impl.cu:338-435) ----
+ * geom/binning/image buffers are the ones the forward filled; R is the forward's num_rendered.
+ * `workspace_resize` provides the backward's own scratch (per-instance partial sums). */
+int c3dgs_rasterize_gaussians_backward(const c3dgs_raster_params* p, const int32_t* radii,
+                                       const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                                       int32_t R, const float* dL_dout_color /*[3,H,W]*/,
+                                       c3dgs_resize_fn workspace_resize, void* workspace_user,
+                                       const c3dgs_raster_grads* grads, void* stream);
+
+/* ---- _C.rasterize_gaussians_backward_indexed (rasterize_points_indexed.cu:125-218 -> rasterizer_impl.cu:590-697) */
+int c3dgs_rasterize_gaussians_backward_indexed(const c3dgs_raster_params* p, const int32_t* radii,
+                                               const void* geom_buffer, const void* binning_buffer,
+                                               const void* image_buffer, int32_t R, const float* dL_dout_color,
+                                               c3dgs_resize_fn workspace_resize, void* workspace_user,
+                                               const c3dgs_raster_grads* grads, void* stream);
+
+/* ---- weighted_distance._C.weightedDistance (weighted_distance.cu:46-93) ----
+ * coefs [N,K], codebook [C,K] row-major fp32 -> min squared distance [N] and argmin [N] (int64).
+ * Exact reference semantics: fp32 k-ordered FMA chain, strict '<' (lowest index wins ties).
+ * gather (optional, may be NULL): int64 [N] row indices into coefs, i.e. row n is coefs[gather[n]]
+ * (fuses `features[batch]` of compression/vq.py:70). */
+int c3dgs_weighted_distance(int64_t N, int32_t C, int32_t K, const float* coefs, const int64_t* gather,
+                            const float* codebook, float* out_dist, int64_t* out_idx, void* stream);
+
+/* ---- VectorQuantize.update, split at the point where a sharded run all-reduces (compression/vq.py:28-35) ----
+ * accumulate: S[k, 0..D) += w_n * x_n ; S[k, D] += w_n for k = idx[n];  *dist_sum += sum_n dist[n] (may be NULL).
+ * S [K, D+1] fp32 must be zeroed by the caller (it is the all-reduce payload). */
+int c3dgs_vq_accumulate(int64_t B, int32_t K, int32_t D, const float* x, const float* w,
+                        const int64_t* gather /*NULL, or row n of x and w is [gather[n]]*/,
+                        const int64_t* idx, const float* dist, float* S, double* dist_sum, void* stream);
+
+/* apply: entry_importance = decay*entry_importance + alpha*S[:,D];
+ *        codebook = decay*codebook + alpha * S[:, :D] / (S[:,D] + eps)        (ema_inplace, vq.py:45-46)
+ * then, if scale_normalize (D>=6): codebook /= (cb[:,0]+cb[:,3]+cb[:,5])[:,None]   (vq.py:73-77). */
+int c3dgs_vq_apply(int32_t K, int32_t D, const float* S, float* codebook, float* entry_importance,
+                   float decay, float alpha, float eps, int32_t scale_normalize, void* stream);
+
+/* ---- introspection (tests and profiling only) ---- */
+typedef struct c3dgs_geom_layout {   /* byte offsets into the geometry buffer for P Gaussians */
+    size_t total_bytes;
+    size_t splat;          /* float4[3*P]: {x, y, conic_a, conic_b} {conic_c, opacity, r, g} {b, bits(offset_excl), bits(rect_lo), bits(rect_hi)} */
+    size_t depths;         /* float[P]                                                     */
+    size_t tiles_touched;  /* uint32[P]                                                    */
+    size_t point_offsets;  /* uint32[P] inclusive scan                                     */
+    size_t rects;          /* uint16[4*P]: xmin, ymin, xmax, ymax (tile units)             */
+    size_t clamped;        /* uint8[P] bit c set = channel c was clamped                   */
+    size_t scan_temp;      /* rocPRIM scan temporary storage                               */
+    size_t scan_temp_bytes;
+} c3dgs_geom_layout;
+
+typedef struct c3dgs_binning_layout { /* byte offsets into the binning buffer for R instances */
+    size_t total_bytes;
+    size_t keys_unsorted;   /* uint64[R]                                                   */
+    size_t values_unsorted; /* uint32[R]                                                   */
+    size_t keys_sorted;     /* uint64[R]                                                   */
+    size_t point_list;      /* uint32[R] sorted Gaussian ids                               */
+    size_t sort_temp;
+    size_t sort_temp_bytes;
+} c3dgs_binning_layout;
+
+typedef struct c3dgs_image_layout {   /* byte offsets into the image buffer                  */
+    size_t total_bytes;
+    size_t final_T;    /* float[W*H]                                                       */
+    size_t n_contrib;  /* uint32[W*H]                                                      */
+    size_t ranges;     /* uint32[2*T]                                                      */
+    size_t tile_used;  /* uint32[T] max n_contrib over the tile's pixels                   */
+} c3dgs_image_layout;
+
+int c3dgs_get_geom_layout(int32_t P, c3dgs_geom_layout* out);
+int c3dgs_get_binning_layout(int32_t R, int32_t W, int32_t H, c3dgs_binning_layout* out);
+int c3dgs_get_image_layout(int32_t W, int32_t H, c3dgs_image_layout* out);
+size_t c3dgs_backward_workspace_bytes(int32_t P, int32_t R);
+
+const char* c3dgs_last_error(void);
+int c3dgs_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C3DGS_HIP_H */

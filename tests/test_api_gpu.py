@@ -1,0 +1,92 @@
+"""-m gpu: the drop-in Python surface (reference diff_gaussian_rasterization_no_camera/__init__.py) end to end
+through torch.autograd, for both module classes."""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases, gpu_util, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(hip, intr, ev, clamp=True, bg=(0.2, 0.4, 0.1), deg=3):
+    return hip.GaussianRasterizationSettings(intrinsic=intr.cuda(), extrinsic_vector=ev.cuda(),
+                                             bg=torch.tensor(bg, device="cuda"), scale_modifier=1.0, sh_degree=deg,
+                                             prefiltered=False, debug=False, clamp_color=clamp)
+
+
+def test_rasterizer_module_autograd(hip, orc):
+    W, H, focal = 200, 136, 125.0
+    ev_t = (0.05, -0.03, 0.02, 0.99, 0.1, -0.05, 0.2)
+    intr, ev = synth.camera(W, H, focal, extrinsic_vector=ev_t)
+    inp, cam, _ = cases.make_case("base")
+    rs = _settings(hip, intr, ev)
+    rast = hip.GaussianRasterizer(rs)
+    leaves = {k: inp[k].cuda().requires_grad_() for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    visible = rast.markVisible(leaves["means3D"], extrinsic_vector=ev.cuda())
+    assert visible.dtype == torch.bool and visible.all()
+    color, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], shs=leaves["shs"],
+                        scales=leaves["scales"], rotations=leaves["rotations"], extrinsic_vector=ev.cuda())
+    assert color.shape == (3, H, W) and radii.dtype == torch.int32 and radii.shape == (4000,)
+    dL = synth.grad_image(W, H)
+    (color * dL.cuda()).sum().backward()
+    # the module builds its own camera matrices on the host; they must equal the oracle's camera set-up
+    st = cases.oracle_forward(inp, cam)
+    np.testing.assert_array_equal(radii.cpu().numpy(), st.radii)
+    ref = orc.rasterize_backward(st, dL.numpy())
+    pairs = dict(means3D="dL_dmeans3D", opacities="dL_dopacity", shs="dL_dsh", scales="dL_dscales", rotations="dL_drotations")
+    for k, r in pairs.items():
+        assert gpu_util.rel_inf(leaves[k].grad.cpu().numpy(), ref[r].reshape(leaves[k].shape)) <= 1e-4, k
+    assert gpu_util.rel_inf(means2D.grad.cpu().numpy(), ref["dL_dmeans2D"]) <= 1e-4
+
+
+def test_indexed_module_autograd_and_camera_grad(hip, orc):
+    W, H, focal = 200, 136, 125.0
+    ev_t = (0.05, -0.03, 0.02, 0.99, 0.1, -0.05, 0.2)
+    intr, ev = synth.camera(W, H, focal, extrinsic_vector=ev_t)
+    inp, cam, _ = cases.make_case("indexed")
+    rs = _settings(hip, intr, ev)
+    for optimize_camera in (False, True):
+        rast = hip.GaussianRasterizerIndexed(rs, optimize_camera=optimize_camera)
+        leaves = {k: inp[k].cuda().requires_grad_() for k in ("means3D", "opacities", "shs", "scales", "scale_factors", "rotations")}
+        means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        evg = ev.cuda().requires_grad_(optimize_camera)
+        color, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                            sh_indices=inp["sh_indices"].cuda(), g_indices=inp["g_indices"].cuda(), shs=leaves["shs"],
+                            scales=leaves["scales"], scale_factors=leaves["scale_factors"], rotations=leaves["rotations"],
+                            extrinsic_vector=evg)
+        dL = synth.grad_image(W, H)
+        (color * dL.cuda()).sum().backward()
+        st = cases.oracle_forward(inp, cam)
+        ref = orc.rasterize_backward(st, dL.numpy())
+        pairs = dict(means3D="dL_dmeans3D", opacities="dL_dopacity", shs="dL_dsh", scales="dL_dscales",
+                     scale_factors="dL_dscale_factors", rotations="dL_drotations")
+        for k, r in pairs.items():
+            assert gpu_util.rel_inf(leaves[k].grad.cpu().numpy(), ref[r].reshape(leaves[k].shape)) <= 1e-4, k
+        if optimize_camera:
+            assert evg.grad is not None and evg.grad.shape == (7,) and torch.isfinite(evg.grad).all()
+        else:
+            assert evg.grad is None
+
+
+def test_no_grad_render_and_error_paths(hip):
+    W, H, focal = 200, 136, 125.0
+    intr, ev = synth.camera(W, H, focal)
+    inp, cam, _ = cases.make_case("base")
+    rast = hip.GaussianRasterizer(_settings(hip, intr, ev))
+    m = inp["means3D"].cuda()
+    with torch.no_grad():
+        color, radii = rast(means3D=m, means2D=torch.zeros_like(m), opacities=inp["opacities"].cuda(), shs=inp["shs"].cuda(),
+                            scales=inp["scales"].cuda(), rotations=inp["rotations"].cuda(), extrinsic_vector=ev.cuda())
+    assert torch.isfinite(color).all()
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        rast(means3D=m, means2D=m, opacities=inp["opacities"].cuda(), scales=inp["scales"].cuda(), rotations=inp["rotations"].cuda())
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+        rast(means3D=m, means2D=m, opacities=inp["opacities"].cuda(), shs=inp["shs"].cuda())
+    with pytest.raises(RuntimeError, match=r"means3D must have dimensions \(num_points, 3\)"):
+        rast(means3D=m[:, :2].contiguous(), means2D=m, opacities=inp["opacities"].cuda(), shs=inp["shs"].cuda(),
+             scales=inp["scales"].cuda(), rotations=inp["rotations"].cuda(), extrinsic_vector=ev.cuda())
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        rast(means3D=inp["means3D"], means2D=m, opacities=inp["opacities"].cuda(), shs=inp["shs"].cuda(),
+             scales=inp["scales"].cuda(), rotations=inp["rotations"].cuda(), extrinsic_vector=ev.cuda())

@@ -1,0 +1,118 @@
+"""-m gpu parity tests for the VQ path: weightedDistance is BIT-EXACT (fp32 distances and int64 indices) against
+the oracle's k-ordered FMA chain; the Lloyd update matches to 1e-5 relative (fp32 atomics vs float64 sums)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(N, C, K, seed, scale=0.1):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(N, K, generator=g) * scale).float()
+    cb = (torch.randn(C, K, generator=g) * scale).float()
+    return x, cb
+
+
+@pytest.mark.parametrize("N,C,K", [(1000, 256, 12), (5000, 4096, 48), (3001, 2048, 6), (777, 100, 48), (513, 33, 5),
+                                   (64, 1, 48), (2000, 300, 27), (1, 7, 6)])
+def test_weighted_distance_bit_exact(hip, orc, N, C, K):
+    x, cb = _data(N, C, K, seed=N + C + K)
+    d_ref, i_ref = orc.weighted_distance(x.numpy(), cb.numpy())
+    d, i = hip.weightedDistance(x.cuda(), cb.cuda())
+    assert d.dtype == torch.float32 and i.dtype == torch.int64 and d.is_cuda
+    np.testing.assert_array_equal(i.cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), d_ref.view(np.uint32))
+
+
+def test_weighted_distance_ties_lowest_index_wins(hip, orc):
+    x, cb = _data(300, 64, 12, seed=1)
+    cb = torch.cat([cb, cb, cb[:10]], 0).contiguous()          # every codeword duplicated: strict '<' keeps the first
+    d, i = hip.weightedDistance(x.cuda(), cb.cuda())
+    d_ref, i_ref = orc.weighted_distance(x.numpy(), cb.numpy())
+    np.testing.assert_array_equal(i.cpu().numpy(), i_ref)
+    assert i.max().item() < 64
+
+
+def test_weighted_distance_gather(hip, orc):
+    x, cb = _data(4000, 512, 48, seed=2)
+    g = torch.Generator().manual_seed(3)
+    batch = torch.randint(0, 4000, (2500,), generator=g)
+    d, i = hip.weightedDistance(x.cuda(), cb.cuda(), gather=batch.cuda())
+    d_ref, i_ref = orc.weighted_distance(x[batch].numpy(), cb.numpy())
+    np.testing.assert_array_equal(i.cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), d_ref.view(np.uint32))
+
+
+def test_weighted_distance_errors(hip):
+    x, cb = _data(10, 4, 6, seed=0)
+    with pytest.raises(RuntimeError, match="dimension 2"):
+        hip.weightedDistance(x.cuda()[0], cb.cuda())
+    with pytest.raises(RuntimeError, match="same number of channels"):
+        hip.weightedDistance(x.cuda(), cb.cuda()[:, :5])
+    with pytest.raises(RuntimeError, match="GPU"):
+        hip.weightedDistance(x, cb)
+    d, i = hip.weightedDistance(x.cuda()[:0], cb.cuda())
+    assert d.shape == (0,) and i.shape == (0,)
+
+
+@pytest.mark.parametrize("D,K,scale_normalize", [(12, 256, False), (48, 512, False), (6, 128, True)])
+def test_vq_update_matches_oracle(hip, orc, D, K, scale_normalize):
+    g = torch.Generator().manual_seed(11)
+    B = 20000
+    x = (torch.randn(B, D, generator=g) * 0.1).float()
+    if D == 6:
+        x[:, [0, 3, 5]] = x[:, [0, 3, 5]].abs() + 0.2
+    w = torch.rand(B, generator=g).pow(4).float()
+    cb0 = x[torch.randperm(B, generator=g)[:K]].clone().contiguous()
+    vqm = hip.VectorQuantize(D, K, decay=0.8).cuda()
+    vqm.codebook.data = cb0.cuda().clone()
+    cb_ref = cb0.numpy().copy()
+    ent_ref = np.zeros(K, np.float32)
+    for step in range(3):
+        md = vqm.update(x.cuda(), w.cuda())
+        if scale_normalize:
+            tr = vqm.codebook[:, [0, 3, 5]].sum(-1)
+            vqm.codebook /= tr[:, None]
+        md_ref, ix_ref, mean_ref = orc.vq_update(x.numpy(), w.numpy(), cb_ref, ent_ref, 0.8, 1e-5)
+        if scale_normalize:
+            from oracle.oracle import lib, _p, _f32p
+            lib().orc_vq_trace_normalize(K, D, _p(cb_ref, _f32p))
+        np.testing.assert_allclose(vqm.codebook.data.cpu().numpy(), cb_ref, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(vqm.entry_importance.data.cpu().numpy(), ent_ref, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(md.cpu().numpy(), md_ref, rtol=1e-5, atol=1e-9)
+
+
+def test_vq_features_matches_oracle(hip, orc):
+    """Config 1 of BASELINE.json (10k Gaussians, SH degree 1 -> D=12, K=256), RNG draws passed as data."""
+    g = torch.Generator().manual_seed(0)
+    N, D, K, steps, chunk = 10_000, 12, 256, 20, 2 ** 12
+    f = (torch.randn(N, D, generator=g) * 0.1).float()
+    imp = torch.rand(N, generator=g).pow(4).float()
+    init = torch.rand(K, D, generator=g)
+    batches = [torch.randint(0, N, (chunk,), generator=g) for _ in range(steps)]
+    cb, idx, errs = hip.vq_features(f.cuda(), imp.cuda(), K, chunk, steps, batches=batches, init_rand=init, silent=True,
+                                    return_errors=True)
+    cb_ref, idx_ref, err_ref, _ = orc.vq_features(f.numpy(), imp.numpy(), K, init.numpy(), [b.numpy() for b in batches])
+    np.testing.assert_allclose(cb.cpu().numpy(), cb_ref, rtol=1e-4, atol=1e-6)
+    agree = (idx.cpu().numpy() == idx_ref).mean()
+    assert agree >= 0.999, agree
+    np.testing.assert_allclose(np.array(errs), err_ref, rtol=1e-4)
+
+
+def test_weighted_distance_full_size_properties(hip):
+    """BASELINE.json config 4 colour shape (batch 2^18 x 4096 x 48): checked through properties the domain
+    offers: the returned distance equals the exact distance to the returned codeword, no sampled codeword is
+    closer, and codewords themselves map to distance 0 at their own (lowest duplicate) index."""
+    g = torch.Generator().manual_seed(5)
+    N, C, K = 2 ** 18, 4096, 48
+    x = (torch.randn(N, K, generator=g) * 0.1).float().cuda()
+    cb = (torch.randn(C, K, generator=g) * 0.1).float().cuda()
+    d, i = hip.weightedDistance(x, cb)
+    exact = ((x - cb[i]) ** 2).sum(-1)
+    torch.testing.assert_close(d, exact, rtol=1e-5, atol=1e-7)
+    probe = torch.randint(0, C, (64,), generator=g).cuda()
+    other = ((x[:, None, :] [:4096] - cb[probe][None]) ** 2).sum(-1)
+    assert (d[:4096, None] <= other * (1 + 1e-5) + 1e-7).all()
+    d2, i2 = hip.weightedDistance(cb, cb)
+    assert (d2 == 0).all() and (i2 == torch.arange(C, device="cuda")).all()
