@@ -59,6 +59,7 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
 
     if (P == 0) { // reference returns zero-filled outputs (rasterize_points.cu:69-70,82)
         C3DGS_HIP_TRY(hipMemsetAsync(out_color, 0, (size_t)3 * W * H * sizeof(float), s));
+        C3DGS_HIP_TRY(hipMemsetAsync(img_base, 0, IL.total_bytes, s));
         return C3DGS_OK;
     }
     if (!radii) return fail(C3DGS_E_INVALID, "radii is required");
