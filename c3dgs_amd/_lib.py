@@ -44,6 +44,10 @@ class BinningLayout(C.Structure):
         "total_bytes", "keys_unsorted", "values_unsorted", "keys_sorted", "point_list", "sort_temp", "sort_temp_bytes")]
 
 
+class StageTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("count", C.c_int64)]
+
+
 class ImageLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("total_bytes", "final_T", "n_contrib", "ranges", "tile_used")]
 
@@ -71,6 +75,8 @@ PROTOTYPES = {
     "c3dgs_get_binning_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(BinningLayout)]),
     "c3dgs_get_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(ImageLayout)]),
     "c3dgs_backward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "c3dgs_profile_enable": (C.c_int, [C.c_int]),
+    "c3dgs_profile_read": (C.c_int, [C.POINTER(StageTime), C.c_int]),
     "c3dgs_last_error": (C.c_char_p, []),
     "c3dgs_abi_version": (C.c_int, []),
 }
@@ -102,3 +108,14 @@ def check(rc):
     if rc != 0:
         msg = lib().c3dgs_last_error()
         raise RuntimeError((msg or b"unknown error").decode("utf-8", "replace"))
+
+
+def profile_enable(on=True):
+    lib().c3dgs_profile_enable(1 if on else 0)
+
+
+def profile_read():
+    """-> {stage: (total_ms, count)} since the last read (synchronises the recorded events)."""
+    arr = (StageTime * 32)()
+    n = lib().c3dgs_profile_read(arr, 32)
+    return {arr[i].name.decode(): (float(arr[i].total_ms), int(arr[i].count)) for i in range(n)}

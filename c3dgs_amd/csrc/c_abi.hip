@@ -2,11 +2,49 @@
 // Stage order follows the reference's Rasterizer::forward / backward (cuda_rasterizer/rasterizer_impl.cu:194-334,
 // 338-435, 440-586, 590-697); the stages themselves are the gfx950 kernels in this directory.
 #include "common.hpp"
+#include <mutex>
+#include <vector>
 
 namespace c3dgs {
 
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
+
+// ---- optional per-stage timing with HIP events recorded on the caller's stream (bench.py's roofline leg).
+// Disabled by default: zero cost. When enabled, every stage launch is bracketed by two events; nothing
+// synchronises until c3dgs_profile_read().
+enum Stage { ST_MARK_VISIBLE, ST_PREPROCESS, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_ZERO_PARTIALS,
+             ST_RENDER_BWD, ST_BWD_PREPROCESS, ST_WDIST, ST_VQ_ACC, ST_VQ_APPLY, ST_COUNT };
+static const char* kStageNames[ST_COUNT] = { "mark_visible", "preprocess", "scan", "duplicate_with_keys", "sort",
+                                             "identify_ranges", "render_forward", "zero_partials", "render_backward",
+                                             "backward_preprocess", "weighted_distance", "vq_accumulate", "vq_apply" };
+struct ProfRec { int stage; hipEvent_t a, b; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+
+struct StageTimer {
+    bool on; int stage; hipStream_t s; hipEvent_t a{}, b{};
+    StageTimer(int stage_, hipStream_t s_) : on(g_prof_on), stage(stage_), s(s_)
+    {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        auto get = [&](hipEvent_t& e) {
+            if (!g_prof_pool.empty()) { e = g_prof_pool.back(); g_prof_pool.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) on = false;
+        };
+        get(a); get(b);
+        if (on) (void)hipEventRecord(a, s);
+    }
+    ~StageTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(b, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_recs.push_back({ stage, a, b });
+    }
+};
 
 static int validate(const c3dgs_raster_params* p, bool indexed, bool is_backward)
 {
@@ -69,9 +107,10 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     if (!geom_base) return fail(C3DGS_E_ALLOC, "geometry buffer allocation failed");
     const GeomPtrs g = geom_ptrs(geom_base, P);
 
-    launch_preprocess(p, g, radii, s);                                               // K2 / K2i
+    { StageTimer t_(ST_PREPROCESS, s); launch_preprocess(p, g, radii, s); }          // K2 / K2i
     C3DGS_STAGE("preprocess", p.debug, s);
-    C3DGS_HIP_TRY(run_inclusive_scan(g.scan_temp, g.scan_temp_bytes, g.tiles_touched, g.point_offsets, P, s)); // K3
+    { StageTimer t_(ST_SCAN, s);
+      C3DGS_HIP_TRY(run_inclusive_scan(g.scan_temp, g.scan_temp_bytes, g.tiles_touched, g.point_offsets, P, s)); } // K3
     C3DGS_STAGE("scan", p.debug, s);
     uint32_t R_u = 0;                                                                // K4: the one host sync
     C3DGS_HIP_TRY(hipMemcpyAsync(&R_u, g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -87,16 +126,18 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
 
     C3DGS_HIP_TRY(hipMemsetAsync(img.ranges, 0, (size_t)T * sizeof(uint2), s));      // K7
     if (R > 0) {
-        launch_duplicate_with_keys(P, g, radii, b, gx, s);                           // K5
+        { StageTimer t_(ST_DUPLICATE, s); launch_duplicate_with_keys(P, g, radii, b, gx, s); } // K5
         C3DGS_STAGE("duplicate_with_keys", p.debug, s);
         const int end_bit = 32 + (int)higher_msb((uint32_t)T);
-        C3DGS_HIP_TRY(run_sort_pairs(b.sort_temp, b.sort_temp_bytes, b.keys_unsorted, b.keys_sorted, b.values_unsorted,
-                                     b.point_list, R, end_bit, s));                  // K6
+        { StageTimer t_(ST_SORT, s);
+          C3DGS_HIP_TRY(run_sort_pairs(b.sort_temp, b.sort_temp_bytes, b.keys_unsorted, b.keys_sorted, b.values_unsorted,
+                                       b.point_list, R, end_bit, s)); }              // K6
         C3DGS_STAGE("sort", p.debug, s);
-        launch_identify_ranges(R, b.keys_sorted, img.ranges, s);                     // K8
+        { StageTimer t_(ST_RANGES, s); launch_identify_ranges(R, b.keys_sorted, img.ranges, s); } // K8
         C3DGS_STAGE("identify_ranges", p.debug, s);
     }
-    launch_render_forward(W, H, img, b.point_list, g.splat, nullptr, p.background, out_color, s); // K9
+    { StageTimer t_(ST_RENDER_FWD, s);
+      launch_render_forward(W, H, img, b.point_list, g.splat, nullptr, p.background, out_color, s); } // K9
     C3DGS_STAGE("render_forward", p.debug, s);
     return C3DGS_OK;
 }
@@ -130,13 +171,14 @@ static int backward_impl(const c3dgs_raster_params* pp, bool indexed, const int3
     float* partials = (float*)ws_resize(ws_user, ws_bytes);
     if (!partials) return fail(C3DGS_E_ALLOC, "backward workspace allocation failed");
 
-    C3DGS_HIP_TRY(hipMemsetAsync(partials, 0, ws_bytes, s));
+    { StageTimer t_(ST_ZERO_PARTIALS, s); C3DGS_HIP_TRY(hipMemsetAsync(partials, 0, ws_bytes, s)); }
     if (R > 0) {
         const BinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), R, W, H);
-        launch_render_backward(W, H, img, b.point_list, g.splat, nullptr, p.background, dL_dout_color, partials, s); // K10
+        { StageTimer t_(ST_RENDER_BWD, s);
+          launch_render_backward(W, H, img, b.point_list, g.splat, nullptr, p.background, dL_dout_color, partials, s); } // K10
         C3DGS_STAGE("render_backward", p.debug, s);
     }
-    launch_backward_preprocess(p, radii, g, partials, *grads, s);                    // K11 + K12(i)
+    { StageTimer t_(ST_BWD_PREPROCESS, s); launch_backward_preprocess(p, radii, g, partials, *grads, s); } // K11 + K12(i)
     C3DGS_STAGE("backward_preprocess", p.debug, s);
     return C3DGS_OK;
 }
@@ -148,6 +190,45 @@ using namespace c3dgs;
 extern "C" {
 
 const char* c3dgs_last_error(void) { return g_last_error.c_str(); }
+
+int c3dgs_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return C3DGS_OK;
+}
+
+int c3dgs_profile_read(c3dgs_stage_time* out, int capacity)
+{
+    std::vector<ProfRec> recs;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        recs.swap(g_prof_recs);
+    }
+    double total[ST_COUNT] = { 0 };
+    long long count[ST_COUNT] = { 0 };
+    for (auto& r : recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            total[r.stage] += (double)ms;
+            count[r.stage]++;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        for (auto& r : recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+    }
+    int n = 0;
+    for (int i = 0; i < ST_COUNT && n < capacity; i++) {
+        if (!count[i]) continue;
+        std::memset(&out[n], 0, sizeof(out[n]));
+        std::strncpy(out[n].name, kStageNames[i], sizeof(out[n].name) - 1);
+        out[n].total_ms = total[i];
+        out[n].count = count[i];
+        n++;
+    }
+    return n;
+}
 int c3dgs_abi_version(void) { return C3DGS_ABI_VERSION; }
 
 int c3dgs_get_geom_layout(int32_t P, c3dgs_geom_layout* out)
@@ -181,7 +262,7 @@ int c3dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
     if (P < 0) return fail(C3DGS_E_INVALID, "P must be >= 0");
     if (P == 0) return C3DGS_OK;
     if (!means3D || !viewmatrix || !present) return fail(C3DGS_E_INVALID, "means3D, viewmatrix and present are required");
-    launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+    { StageTimer t_(ST_MARK_VISIBLE, (hipStream_t)stream); launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream); }
     C3DGS_STAGE("mark_visible", 0, (hipStream_t)stream);
     return C3DGS_OK;
 }
@@ -226,8 +307,11 @@ int c3dgs_weighted_distance(int64_t N, int32_t C, int32_t K, const float* coefs,
     if (N < 0 || C < 0 || K <= 0) return fail(C3DGS_E_INVALID, "coefs and codebook must have same number of channels");
     if (N == 0) return C3DGS_OK;
     if (!coefs || !codebook || !out_dist || !out_idx) return fail(C3DGS_E_INVALID, "ceofs and codebook must have dimension 2");
-    if (launch_weighted_distance(N, C, K, coefs, gather, codebook, out_dist, out_idx, (hipStream_t)stream))
-        return fail(C3DGS_E_INVALID, "unsupported channel count");
+    {
+        StageTimer t_(ST_WDIST, (hipStream_t)stream);
+        if (launch_weighted_distance(N, C, K, coefs, gather, codebook, out_dist, out_idx, (hipStream_t)stream))
+            return fail(C3DGS_E_INVALID, "unsupported channel count");
+    }
     C3DGS_STAGE("weighted_distance", 0, (hipStream_t)stream);
     return C3DGS_OK;
 }
@@ -238,7 +322,7 @@ int c3dgs_vq_accumulate(int64_t B, int32_t K, int32_t D, const float* x, const f
     if (B < 0 || K <= 0 || D <= 0) return fail(C3DGS_E_INVALID, "bad sizes");
     if (B == 0) return C3DGS_OK;
     if (!x || !w || !idx || !S) return fail(C3DGS_E_INVALID, "x, w, idx and S are required");
-    launch_vq_accumulate(B, K, D, x, w, gather, idx, dist, S, dist_sum, (hipStream_t)stream);
+    { StageTimer t_(ST_VQ_ACC, (hipStream_t)stream); launch_vq_accumulate(B, K, D, x, w, gather, idx, dist, S, dist_sum, (hipStream_t)stream); }
     C3DGS_STAGE("vq_accumulate", 0, (hipStream_t)stream);
     return C3DGS_OK;
 }
@@ -247,7 +331,7 @@ int c3dgs_vq_apply(int32_t K, int32_t D, const float* S, float* codebook, float*
                    float alpha, float eps, int32_t scale_normalize, void* stream)
 {
     if (K <= 0 || D <= 0 || !S || !codebook || !entry_importance) return fail(C3DGS_E_INVALID, "bad arguments");
-    launch_vq_apply(K, D, S, codebook, entry_importance, decay, alpha, eps, scale_normalize, (hipStream_t)stream);
+    { StageTimer t_(ST_VQ_APPLY, (hipStream_t)stream); launch_vq_apply(K, D, S, codebook, entry_importance, decay, alpha, eps, scale_normalize, (hipStream_t)stream); }
     C3DGS_STAGE("vq_apply", 0, (hipStream_t)stream);
     return C3DGS_OK;
 }

@@ -178,6 +178,18 @@ int c3dgs_get_binning_layout(int32_t R, int32_t W, int32_t H, c3dgs_binning_layo
 int c3dgs_get_image_layout(int32_t W, int32_t H, c3dgs_image_layout* out);
 size_t c3dgs_backward_workspace_bytes(int32_t P, int32_t R);
 
+/* ---- optional per-stage timing (HIP events on the caller's stream; used by bench.py's roofline leg) ----
+ * c3dgs_profile_enable(1) makes every stage launch record a start/stop event pair; c3dgs_profile_read()
+ * synchronises those events, returns one record per stage seen since the last read (count returned, at
+ * most `capacity`) and resets the accumulators. Disabled (the default) it costs nothing. */
+typedef struct c3dgs_stage_time {
+    char name[32];
+    double total_ms;
+    int64_t count;
+} c3dgs_stage_time;
+int c3dgs_profile_enable(int on);
+int c3dgs_profile_read(c3dgs_stage_time* out, int capacity);
+
 const char* c3dgs_last_error(void);
 int c3dgs_abi_version(void);
 
