@@ -824,3 +824,19 @@ void orc_vq_trace_normalize(int K, int D, float* codebook)
         for (int d = 0; d < D; d++) c[d] = c[d] / tr;
     }
 }
+
+/* ---------------------------------------------------------------- test hooks (golden-vector pinning) */
+void orc_test_color_from_sh(int n, int deg, int M, const float* pos, const float* campos, const float* sh,
+                            int clamp_color, uint8_t* clamped, float* rgb)
+{
+    f3 cp = { campos[0], campos[1], campos[2] };
+    for (int i = 0; i < n; i++) {
+        f3 p = { pos[3 * i], pos[3 * i + 1], pos[3 * i + 2] };
+        color_from_sh(deg, p, cp, sh + (size_t)i * M * 3, clamp_color, clamped + 3 * i, rgb + 3 * i);
+    }
+}
+
+void orc_test_cov3d(int n, const float* scales, float mod, const float* rots, float* cov)
+{
+    for (int i = 0; i < n; i++) cov3d_from_scale_rot(scales + 3 * i, mod, rots + 4 * i, cov + 6 * i);
+}

@@ -108,6 +108,11 @@ void orc_vq_trace_normalize(int K, int D, float* codebook);
 
 int orc_num_threads(void);
 
+/* test hooks: expose the per-Gaussian SH->RGB and cov3D helpers for golden-vector pinning */
+void orc_test_color_from_sh(int n, int deg, int M, const float* pos, const float* campos, const float* sh,
+                            int clamp_color, uint8_t* clamped, float* rgb);
+void orc_test_cov3d(int n, const float* scales, float mod, const float* rots, float* cov);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,10 @@ def lib():
         _lib.orc_get_higher_msb.restype = C.c_uint32
         _lib.orc_get_higher_msb.argtypes = [C.c_uint32]
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_test_color_from_sh.restype = None
+        _lib.orc_test_color_from_sh.argtypes = [C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, _u8p, _f32p]
+        _lib.orc_test_cov3d.restype = None
+        _lib.orc_test_cov3d.argtypes = [C.c_int, _f32p, C.c_float, _f32p, _f32p]
     return _lib
 
 
@@ -317,3 +321,23 @@ def vq_features(features, importance, codebook_size, init_rand, batches, decay=0
             lib().orc_vq_trace_normalize(cb.shape[0], cb.shape[1], _p(cb, _f32p))
     _, idx = weighted_distance(f, cb)
     return cb, idx, np.asarray(errors), ent
+
+
+# ----------------------------------------------------------------------------- test hooks
+def color_from_sh(deg, pos, campos, sh, clamp_color=False):
+    """forward.cu:20-79 for n Gaussians: sh [n,M,3], pos [n,3] -> (rgb [n,3], clamped [n,3])."""
+    pos, sh, campos = _f32(pos), _f32(sh), _f32(campos)
+    n, M = sh.shape[0], sh.shape[1]
+    rgb = np.zeros((n, 3), np.float32)
+    cl = np.zeros((n, 3), np.uint8)
+    lib().orc_test_color_from_sh(n, int(deg), M, _p(pos, _f32p), _p(campos, _f32p), _p(sh, _f32p), int(clamp_color),
+                                 _p(cl, _u8p), _p(rgb, _f32p))
+    return rgb, cl
+
+
+def cov3d(scales, mod, rotations):
+    """forward.cu:126-160 -> [n,6]."""
+    s, q = _f32(scales), _f32(rotations)
+    out = np.zeros((s.shape[0], 6), np.float32)
+    lib().orc_test_cov3d(s.shape[0], _p(s, _f32p), float(mod), _p(q, _f32p), _p(out, _f32p))
+    return out

@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by RUNNING the reference's importable Python in the build container.
+
+    python tests/golden/make_golden.py            (needs /root/reference; never runs on the GPU box)
+
+What it pins; the fixtures hold data only (inputs + expected outputs):
+  vq_*.npz       compression/vq.py:vq_features end to end on CPU tensors, with its two missing native deps
+                 shimmed (torch_scatter.scatter == index_add_, weightedDistance == exact direct-difference
+                 argmin) and its RNG draws (rand_like of uniform_init, randint batches) captured as data
+  sh.npz         utils/sh_utils.py:eval_sh                       -> K2's SH->RGB (before +0.5 / clamp)
+  cov3d.npz      utils/general_utils.py:build_covariance_from_scaling_rotation -> K2's cov3D
+  camgrad.npz    the closed-form grad_params block of _RasterizeGaussiansIndexedCamera.backward
+                 (diff_gaussian_rasterization_no_camera/__init__.py:674-844), executed on CPU tensors
+"""
+import os
+import re
+import sys
+import textwrap
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def shim_and_import_vq():
+    sys.path.insert(0, REF)
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter(src, index, dim=0, reduce="sum", dim_size=None):
+        assert reduce == "sum" and dim == 0
+        out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+        return out.index_add_(0, index, src)
+    ts.scatter = scatter
+    sys.modules["torch_scatter"] = ts
+    wd = types.ModuleType("weighted_distance")
+    wdc = types.ModuleType("weighted_distance._C")
+
+    def weightedDistance(x, cb):
+        outd, outi = [], []
+        for s in range(0, x.shape[0], 4096):
+            d = ((x[s:s + 4096, None] - cb[None]) ** 2).sum(-1)
+            m, i = d.min(1)
+            outd.append(m)
+            outi.append(i)
+        return torch.cat(outd), torch.cat(outi)
+    wdc.weightedDistance = weightedDistance
+    wd._C = wdc
+    sys.modules["weighted_distance"] = wd
+    sys.modules["weighted_distance._C"] = wdc
+    import compression.vq as vq
+    torch.cuda.synchronize = lambda *a, **k: None        # vq.py:83 calls it unconditionally
+    return vq
+
+
+def gen_vq(vq, name, N, D, K, steps, chunk, scale_normalize, seed):
+    g = torch.Generator().manual_seed(seed)
+    f = (torch.randn(N, D, generator=g) * 0.1).float()
+    if scale_normalize:
+        f[:, [0, 3, 5]] = f[:, [0, 3, 5]].abs() + 0.2
+    imp = torch.rand(N, generator=g).pow(4).float()
+    draws = {"rand": None, "batches": []}
+    orig_rand_like, orig_randint = torch.rand_like, torch.randint
+
+    def rand_like(t, *a, **k):
+        r = orig_rand_like(t, *a, **k)
+        draws["rand"] = r.clone()
+        return r
+
+    def randint(*a, **k):
+        r = orig_randint(*a, **k)
+        draws["batches"].append(r.clone())
+        return r
+    torch.manual_seed(seed)
+    torch.rand_like, torch.randint = rand_like, randint
+    try:
+        errors = []
+        import builtins
+        cb, idx = vq.vq_features(f, imp, K, chunk, steps, scale_normalize=scale_normalize, silent=True)
+    finally:
+        torch.rand_like, torch.randint = orig_rand_like, orig_randint
+    np.savez_compressed(os.path.join(OUT, name), features=f.numpy(), importance=imp.numpy(), init_rand=draws["rand"].numpy(),
+                        batches=torch.stack(draws["batches"]).numpy().astype(np.int64), codebook=cb.numpy(),
+                        indices=idx.numpy().astype(np.int64), scale_normalize=np.array(int(scale_normalize)),
+                        K=np.array(K))
+    print(name, "codebook", tuple(cb.shape), "steps", len(draws["batches"]))
+
+
+def gen_sh():
+    from utils.sh_utils import eval_sh
+    g = torch.Generator().manual_seed(5)
+    P = 257
+    sh = torch.randn(P, 16, 3, generator=g).float()          # kernel layout [P, M, 3]
+    d = torch.randn(P, 3, generator=g)
+    d = (d / d.norm(dim=1, keepdim=True)).float()
+    out = {}
+    for deg in range(4):
+        out[f"rgb_deg{deg}"] = eval_sh(deg, sh.transpose(1, 2), d).numpy()   # eval_sh wants [..., 3, M]
+    np.savez_compressed(os.path.join(OUT, "sh.npz"), sh=sh.numpy(), dirs=d.numpy(), **out)
+    print("sh.npz")
+
+
+def gen_cov3d():
+    from utils.general_utils import build_covariance_from_scaling_rotation
+    g = torch.Generator().manual_seed(6)
+    P = 300
+    s = torch.exp(torch.randn(P, 3, generator=g) * 0.5 - 3.0).float()
+    q = torch.randn(P, 4, generator=g)
+    q = (q / q.norm(dim=1, keepdim=True)).float()
+    out = {}
+    for mod in (1.0, 1.7):
+        out[f"cov_mod{mod}"] = build_covariance_from_scaling_rotation(s, mod, q).numpy()
+    np.savez_compressed(os.path.join(OUT, "cov3d.npz"), scales=s.numpy(), rotations=q.numpy(), **out)
+    print("cov3d.npz")
+
+
+def gen_camgrad():
+    src = open(os.path.join(REF, "submodules/diff-gaussian-rasterization-no-camera/"
+                                 "diff_gaussian_rasterization_no_camera/__init__.py")).read().split("\n")
+    block = "\n".join(src[673:788])                           # lines 674..788: X,Y,Z ... grad_params[:, 6, 1]
+    block = textwrap.dedent(block).replace('device="cuda"', 'device="cpu"')
+    g = torch.Generator().manual_seed(9)
+    P = 64
+    means3D = torch.cat([torch.randn(P, 2, generator=g), torch.rand(P, 1, generator=g) * 5 + 2], 1).float()
+    intrinsic = torch.tensor([[1.2, 0, 640.0], [0, 0.9, 480.0], [0, 0, 1]], dtype=torch.float32)
+    q = torch.tensor([0.05, -0.03, 0.02, 0.99])
+    ev = torch.cat([q / q.norm(), torch.tensor([0.1, -0.05, 0.2])]).float()
+    ns = dict(torch=torch, means3D=means3D, extrinsic_vector=ev,
+              raster_settings=types.SimpleNamespace(intrinsic=intrinsic))
+    exec(block, ns)
+    gp = ns["grad_params"]
+    du, dv = torch.randn(P, generator=g).float(), torch.randn(P, generator=g).float()
+    grad_mat = torch.stack([(gp[:, p, 0] * du + gp[:, p, 1] * dv).sum() for p in range(7)])
+    np.savez_compressed(os.path.join(OUT, "camgrad.npz"), means3D=means3D.numpy(), intrinsic=intrinsic.numpy(),
+                        extrinsic_vector=ev.numpy(), du=du.numpy(), dv=dv.numpy(), grad_params=gp.numpy(),
+                        grad_mat=grad_mat.numpy())
+    print("camgrad.npz")
+
+
+if __name__ == "__main__":
+    vq = shim_and_import_vq()
+    gen_vq(vq, "vq_color.npz", N=3000, D=12, K=64, steps=12, chunk=1024, scale_normalize=False, seed=0)
+    gen_vq(vq, "vq_cov.npz", N=2500, D=6, K=32, steps=10, chunk=512, scale_normalize=True, seed=1)
+    gen_sh()
+    gen_cov3d()
+    gen_camgrad()

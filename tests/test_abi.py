@@ -1,0 +1,76 @@
+"""CPU: the C-ABI shared library loads without a GPU, exports every symbol include/c3dgs_hip.h declares, and its
+argument validation (no device work) returns the documented codes."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from c3dgs_amd import build, _lib
+    build.build()
+    return _lib.lib()
+
+
+def _declared_symbols():
+    h = open(os.path.join(ROOT, "include", "c3dgs_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(c3dgs_[a-z0-9_]+)\s*\(", h)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(L):
+    from c3dgs_amd import _lib
+    syms = _declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/c3dgs_hip.h but not exported"
+        assert s in _lib.PROTOTYPES, f"{s} has no ctypes prototype"
+    assert L.c3dgs_abi_version() == 1
+
+
+def test_layouts_are_consistent(L):
+    from c3dgs_amd import _lib
+    g = _lib.GeomLayout()
+    assert L.c3dgs_get_geom_layout(1000, C.byref(g)) == 0
+    offs = [g.splat, g.depths, g.tiles_touched, g.point_offsets, g.rects, g.clamped, g.scan_temp]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs) and g.total_bytes > g.scan_temp
+    assert g.depths - g.splat >= 1000 * 48
+    b = _lib.BinningLayout()
+    assert L.c3dgs_get_binning_layout(5000, 1920, 1080, C.byref(b)) == 0
+    assert b.values_unsorted - b.keys_unsorted >= 5000 * 8 and b.total_bytes > b.sort_temp
+    im = _lib.ImageLayout()
+    assert L.c3dgs_get_image_layout(1920, 1080, C.byref(im)) == 0
+    assert im.n_contrib - im.final_T >= 1920 * 1080 * 4 and im.tile_used - im.ranges >= 8160 * 8
+    assert L.c3dgs_backward_workspace_bytes(10, 1000) >= 1000 * 36
+    assert L.c3dgs_get_geom_layout(-1, C.byref(g)) == 1
+
+
+def test_validation_without_gpu(L):
+    from c3dgs_amd import _lib
+    # N == 0 is legal and touches nothing
+    assert L.c3dgs_weighted_distance(0, 4, 6, None, None, None, None, None, None) == 0
+    assert L.c3dgs_weighted_distance(10, 4, 6, None, None, None, None, None, None) == 1
+    assert b"dimension 2" in L.c3dgs_last_error()
+    assert L.c3dgs_mark_visible(0, None, None, None, None, None) == 0
+    assert L.c3dgs_mark_visible(5, None, None, None, None, None) == 1
+    p = _lib.RasterParams()
+    p.P, p.W, p.H = 4, 64, 64
+    n = C.c_int32(0)
+    cb = _lib.RESIZE_FN(lambda u, b: 0)
+    rc = L.c3dgs_rasterize_gaussians(C.byref(p), cb, None, cb, None, cb, None, None, None, C.byref(n), None)
+    assert rc == 1 and b"means3D must have dimensions" in L.c3dgs_last_error()
+    assert L.c3dgs_vq_apply(0, 4, None, None, None, 0.8, 0.2, 1e-5, 0, None) == 1
+    st = (_lib.StageTime * 4)()
+    assert L.c3dgs_profile_read(st, 4) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from c3dgs_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()

@@ -1,0 +1,96 @@
+"""CPU: host-side logic of the drop-in Python surface (no kernels): camera set-up, argument checks, the factored
+camera-pose Jacobian against the reference's closed form (golden vector), module aliasing, and the hard failure on
+CPU tensors (the package has no CPU path)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import c3dgs_amd
+from c3dgs_amd import rasterizer as rz
+from tests import synth
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_camera_matrices_match_oracle_setup(orc):
+    intr, ev = synth.camera(640, 480, 500.0, extrinsic_vector=(0.05, -0.03, 0.02, 0.99, 0.1, -0.05, 0.2))
+    view, proj, campos, tfx, tfy, H, W = rz.camera_matrices(intr, ev, "cpu")
+    cam = orc.camera(intr.numpy(), ev.numpy())
+    np.testing.assert_array_equal(view.numpy(), cam["viewmatrix"])
+    np.testing.assert_allclose(proj.numpy(), cam["projmatrix"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(campos.numpy(), cam["campos"], rtol=1e-5, atol=1e-6)
+    assert (H, W) == (480, 640) and abs(tfx - cam["tan_fovx"]) < 1e-12 and abs(tfy - cam["tan_fovy"]) < 1e-12
+    # W2C^T layout: m[0], m[4], m[8], m[12] is row 0 of W2C; translation in the last ROW
+    np.testing.assert_allclose(view.numpy()[3, :3], [0.1, -0.05, 0.2], rtol=1e-6)
+    # identity pose -> identity matrix
+    np.testing.assert_array_equal(rz.quat_to_mat(torch.tensor([0., 0, 0, 1, 0, 0, 0])).numpy(), np.eye(4, dtype=np.float32))
+    P = rz.getProjectionMatrix(intr)
+    assert P.shape == (4, 4) and P[2, 3] == 1.0 and abs(P[3, 2].item() + 0.010001) < 1e-6   # transposed, znear .01 zfar 100
+
+
+def test_mat_to_quat_roundtrip():
+    ev = torch.tensor([0.05, -0.03, 0.02, 0.99, 0.1, -0.05, 0.2])
+    ev[:4] /= ev[:4].norm()
+    m = rz.quat_to_mat(ev).T
+    q = torch.stack([torch.as_tensor(v) for v in rz.mat_to_quat(m)])
+    np.testing.assert_allclose(q.numpy(), ev.numpy(), atol=1e-6)
+
+
+def test_camera_pose_jacobian_matches_reference_closed_form():
+    d = np.load(os.path.join(G, "camgrad.npz"), allow_pickle=False)
+    got = rz.camera_pose_jacobian_sum(torch.from_numpy(d["means3D"]), torch.from_numpy(d["intrinsic"]),
+                                      torch.from_numpy(d["extrinsic_vector"]), torch.from_numpy(d["du"]),
+                                      torch.from_numpy(d["dv"]))
+    np.testing.assert_allclose(got.numpy(), d["grad_mat"], rtol=2e-4, atol=1e-4)
+
+
+def test_argument_checks_and_no_cpu_path():
+    intr, ev = synth.camera(64, 48, 40.0)
+    rs = c3dgs_amd.GaussianRasterizationSettings(intr, ev, torch.zeros(3), 1.0, 3, False, False, True)
+    rast = c3dgs_amd.GaussianRasterizer(rs)
+    sc = synth.scene(10, 64, 48, 40.0)
+    m = sc["means3D"]
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        rast(m, m, sc["opacities"], scales=sc["scales"], rotations=sc["rotations"])
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        rast(m, m, sc["opacities"], shs=sc["shs"], colors_precomp=m, scales=sc["scales"], rotations=sc["rotations"])
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+        rast(m, m, sc["opacities"], shs=sc["shs"], scales=sc["scales"])
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+        rast(m, m, sc["opacities"], shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=torch.zeros(10, 6))
+    # CPU tensors: the product refuses instead of falling back
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        rast(m, m, sc["opacities"], shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"], extrinsic_vector=ev)
+    with pytest.raises(RuntimeError, match="GPU"):
+        c3dgs_amd.weightedDistance(torch.zeros(4, 6), torch.zeros(2, 6))
+    with pytest.raises(RuntimeError, match="dimension 2"):
+        c3dgs_amd.weightedDistance(torch.zeros(4), torch.zeros(2, 6))
+    with pytest.raises(RuntimeError, match="same number of channels"):
+        c3dgs_amd.weightedDistance(torch.zeros(4, 5), torch.zeros(2, 6))
+    idx = c3dgs_amd.GaussianRasterizerIndexed(rs, optimize_camera=True)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        idx(m, m, sc["opacities"], torch.zeros(10, dtype=torch.long), torch.zeros(10, dtype=torch.long))
+
+
+def test_join_features_and_settings():
+    feats = torch.arange(12.).reshape(6, 2)
+    keep = torch.tensor([True, False, False, True, False, False])
+    cb = torch.tensor([[100., 100.], [200., 200.]])
+    comp, idx = c3dgs_amd.join_features(feats, keep, cb, torch.tensor([0, 1, 1, 0]))
+    assert comp.shape == (4, 2) and idx.tolist() == [2, 0, 1, 3, 1, 0]
+    torch.testing.assert_close(comp[idx][keep], feats[keep])
+    cs = c3dgs_amd.CompressionSettings(4096, 0.0, None, 0.9, 100, 0.8, 2 ** 18)
+    assert cs.codebook_size == 4096 and cs.importance_include is None
+
+
+def test_install_as_reference_modules():
+    c3dgs_amd.install_as_reference_modules()
+    import diff_gaussian_rasterization_no_camera as dgr
+    from weighted_distance._C import weightedDistance
+    assert dgr.GaussianRasterizerIndexed is c3dgs_amd.GaussianRasterizerIndexed and callable(weightedDistance)
+    for n in ("diff_gaussian_rasterization_no_camera", "diff_gaussian_rasterization", "diff_gaussian_rasterization_camera",
+              "weighted_distance", "weighted_distance._C"):
+        sys.modules.pop(n, None)
