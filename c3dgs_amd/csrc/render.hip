@@ -11,8 +11,8 @@
 //    next batch's gather is issued before the current batch is blended;
 //  * early-out is a per-wave ballot plus four LDS flags read after the batch barrier;
 //  * workgroup ids are remapped so that each XCD (own L2) gets a contiguous band of tiles;
-//  * backward: NO global atomics. The 9 per-Gaussian sums are reduced over the wave with DPP row
-//    shifts + row broadcasts, over the 4 waves through LDS, and stored once per (Gaussian, tile)
+//  * backward: NO global atomics. The 9 per-Gaussian sums are reduced over the wave by a transposing
+//    DPP / permlane-swap network shared by 7 Gaussians, over the 4 waves through LDS, and stored once per (Gaussian, tile)
 //    instance into a slot array indexed like duplicate_with_keys' unsorted emission order; the
 //    per-Gaussian kernel (backward_preprocess.hip) then sums a contiguous run of slots. Plain
 //    stores run ~4-5x the chip-wide float-atomic rate on MI355X and the result is bitwise
@@ -38,6 +38,32 @@ __device__ __forceinline__ bool gaussian_alpha(float mx, float my, float ca, flo
     return !(alpha < 1.0f / 255.0f);
 }
 
+// Which of the tile's four 8x8 quadrants (= waves) can this Gaussian touch at all?  A pixel only blends the
+// Gaussian if alpha = min(0.99, o*exp(power)) >= 1/255, i.e. 0.5*d^T C d <= tau with tau = ln(255*o); that ellipse
+// has the axis-aligned half extents sqrt(2 tau C^-1_xx), sqrt(2 tau C^-1_yy). Quadrants outside the (slightly
+// inflated: +1e-4 relative, +0.01 px, far above the fp32 error of the per-pixel test) box cannot contain a
+// contributing pixel, so skipping them changes no result. Bit q = qy*2+qx. Anything non-finite -> no culling.
+__device__ __forceinline__ uint32_t quadrant_mask(const float4 a, const float4 b, float tile_x0, float tile_y0)
+{
+    const float mx = a.x, my = a.y, ca = a.z, cb = a.w, cc = b.x, op = b.y;
+    if (op < (1.0f / 255.0f) * 0.999f) return 0u;          // alpha <= o < 1/255 everywhere
+    const float det = ca * cc - cb * cb;
+    const float tau2 = 2.0f * __logf(255.0f * op) * 1.0001f + 2e-4f;
+    const float ex = sqrtf(tau2 * cc / det) * 1.0001f + 0.01f;
+    const float ey = sqrtf(tau2 * ca / det) * 1.0001f + 0.01f;
+    if (!(det > 0.0f) || !(ex < 1e30f) || !(ey < 1e30f)) return 0xfu;
+    const float lx = mx - ex, hx = mx + ex, ly = my - ey, hy = my + ey;
+    const bool x0 = hx >= tile_x0 && lx <= tile_x0 + 7.0f, x1 = hx >= tile_x0 + 8.0f && lx <= tile_x0 + 15.0f;
+    const bool y0 = hy >= tile_y0 && ly <= tile_y0 + 7.0f, y1 = hy >= tile_y0 + 8.0f && ly <= tile_y0 + 15.0f;
+    return (uint32_t)(x0 && y0) | ((uint32_t)(x1 && y0) << 1) | ((uint32_t)(x0 && y1) << 2) | ((uint32_t)(x1 && y1) << 3);
+}
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2) under the observed
 // round-robin dispatch, so give every XCD one contiguous band of row-major tiles. Speed only.
 __device__ __forceinline__ int tile_of_block(int b, int T)
@@ -57,6 +83,7 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     __shared__ float4 s_b[2][BATCH];
     __shared__ float s_c[2][BATCH];
     __shared__ int s_wdone[2][4];
+    __shared__ unsigned long long s_mask[2][4][4];   // [buf][quadrant][staging wave]: which staged Gaussians reach it
     __shared__ uint32_t s_used;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -67,6 +94,7 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     const float pxf = (float)px, pyf = (float)py;
     bool done = !inside;
     if (tid == 0) s_used = 0;
+    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
@@ -83,6 +111,12 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     for (int r = 0; r < rounds; r++) {
         const int buf = r & 1;
         s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc.x;
+        const uint32_t qm = (r * BATCH + tid < n) ? quadrant_mask(ra, rb, tile_x0, tile_y0) : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned long long bm = __ballot((qm >> q) & 1u);
+            if (lane == 0) s_mask[buf][q][wave] = bm;
+        }
         const bool wave_done = __all(done);
         if (lane == 0) s_wdone[buf][wave] = wave_done;
         __syncthreads();
@@ -93,24 +127,28 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
             ra = splat[3 * (size_t)id]; rb = splat[3 * (size_t)id + 1]; rc = splat[3 * (size_t)id + 2];
         }
         if (wave_done) continue;
-        const int cnt = min(BATCH, n - r * BATCH);
         const uint32_t base = (uint32_t)(r * BATCH);
-        for (int j = 0; j < cnt; j++) {
-            if (__all(done)) break;
-            const float4 a = s_a[buf][j], b = s_b[buf][j];
-            float dx, dy, G, alpha;
-            const bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
-            if (!__any(hit && !done)) continue;
-            if (hit && !done) {
-                const float test_T = Tr * (1.f - alpha);
-                if (test_T < 0.0001f) {
-                    done = true;                 // forward.cu:355-360: stop BEFORE blending this one
-                } else {
-                    const float w = alpha * Tr;
-                    C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(s_c[buf][j], w, C2);
-                    Tr = test_T;
-                    last_contributor = base + (uint32_t)j + 1u;
+        bool wave_all_done = false;
+        for (int c = 0; c < 4 && !wave_all_done; c++) {
+            unsigned long long m = uniform_u64(s_mask[buf][wave][c]);   // scalar: only Gaussians that can reach this quadrant
+            while (m) {
+                const int j = c * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                const float4 a = s_a[buf][j], b = s_b[buf][j];
+                float dx, dy, G, alpha;
+                const bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
+                if (hit && !done) {
+                    const float test_T = Tr * (1.f - alpha);
+                    if (test_T < 0.0001f) {
+                        done = true;             // forward.cu:355-360: stop BEFORE blending this one
+                    } else {
+                        const float w = alpha * Tr;
+                        C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(s_c[buf][j], w, C2);
+                        Tr = test_T;
+                        last_contributor = base + (uint32_t)j + 1u;
+                    }
                 }
+                if (__all(done)) { wave_all_done = true; break; }
             }
         }
     }
@@ -138,27 +176,61 @@ void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* poi
 }
 
 // ---------------------------------------------------------------- backward
-
-// wave64 sum on gfx950 via DPP: 4 row shifts (sum of each 16-lane row lands in its lane 15), then
-// row_bcast15 / row_bcast31 fold the four rows; the total is valid in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v)
-{
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
-    return v + __int_as_float(moved);
-}
-__device__ __forceinline__ float wave_sum_lane63(float v)
-{
-    v = dpp_add<0x111, 0xf>(v); // row_shr:1
-    v = dpp_add<0x112, 0xf>(v); // row_shr:2
-    v = dpp_add<0x114, 0xf>(v); // row_shr:4
-    v = dpp_add<0x118, 0xf>(v); // row_shr:8
-    v = dpp_add<0x142, 0xa>(v); // row_bcast:15 -> rows 1,3
-    v = dpp_add<0x143, 0xc>(v); // row_bcast:31 -> rows 2,3
-    return v;
-}
-
+//
+// Per (wave, Gaussian) the 9 gradient terms must be summed over the wave's 64 pixels. A plain butterfly costs
+// 6 cross-lane adds per value (54 per Gaussian). Instead GROUP_G = 7 Gaussians (63 values + 1 pad) are reduced
+// TOGETHER by a transposing network: at every step a lane pair exchanges halves, each lane keeps half of the
+// values it held and adds its partner's copy of that half, so the live values per lane halve while the lanes
+// summed per value double:
+//    64 -> 32 values  row_ror:8           (lane bit 3 picks the half)        v_add_f32_dpp
+//    32 -> 16         row_half_mirror     (lane bit 2)
+//    16 ->  8         quad_perm [1,0,3,2] (lane bit 0)
+//     8 ->  4         quad_perm [2,3,0,1] (lane bit 1)      -> each lane: 4 values summed over its 16-lane row
+//     4 ->  2         v_permlane16_swap   (lane bit 4)
+//     2 ->  1         v_permlane32_swap   (lane bit 5)      -> lane l holds the wave total of value idx(l)
+// = 60 DPP adds + 120 selects + 3 swaps per 7 Gaussians (~26 per Gaussian instead of ~95), and the 63 results
+// sit in 63 different lanes, so ONE ds_write_b32 stores them all.
 constexpr int NPART = PARTIAL_FLOATS; // 9
+constexpr int GROUP_G = 7;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_take(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+template <int N, int CTRL>
+__device__ __forceinline__ void transpose_reduce_step(float* v, bool hi)
+{
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) {
+        const float keep = hi ? v[k + N / 2] : v[k];
+        const float send = hi ? v[k] : v[k + N / 2];
+        v[k] = keep + dpp_take<CTRL>(send);
+    }
+}
+
+// value index that ends up in lane l after the network (see the table above)
+__device__ __forceinline__ int reduced_index_of_lane(int l)
+{
+    return (((l >> 3) & 1) << 5) | (((l >> 2) & 1) << 4) | ((l & 1) << 3) | (((l >> 1) & 1) << 2) | (((l >> 4) & 1) << 1) |
+           ((l >> 5) & 1);
+}
+
+__device__ __forceinline__ float transpose_reduce_64(float* v, int lane)
+{
+    transpose_reduce_step<64, 0x128>(v, (lane & 8) != 0);  // row_ror:8
+    transpose_reduce_step<32, 0x141>(v, (lane & 4) != 0);  // row_half_mirror
+    transpose_reduce_step<16, 0xB1>(v, (lane & 1) != 0);   // quad_perm [1,0,3,2]
+    transpose_reduce_step<8, 0x4E>(v, (lane & 2) != 0);    // quad_perm [2,3,0,1]
+    // rows: v[0..3] indexed (b1,b0); odd rows keep b1 = 1
+    auto s0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+    auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+    const float w0 = __uint_as_float(s0[0]) + __uint_as_float(s0[1]);
+    const float w1 = __uint_as_float(s1[0]) + __uint_as_float(s1[1]);
+    auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w0), __float_as_uint(w1), false, false);
+    return __uint_as_float(s2[0]) + __uint_as_float(s2[1]);
+}
 
 __global__ void __launch_bounds__(256)
 render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_used,
@@ -173,6 +245,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     __shared__ float4 s_b[BATCH];
     __shared__ float s_c[BATCH];
     __shared__ uint32_t s_slot[BATCH];
+    __shared__ unsigned long long s_mask[4][4];      // [quadrant][staging wave]
     __shared__ float s_part[4][BATCH][NPART];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -197,10 +270,19 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     const float bg_dot = bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;       // backward.cu:460-461
+    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
+    // nothing behind the deepest last_contributor of this wave's 64 pixels can matter to this wave
+    int wave_last = last_contributor;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, o));
+    // where this lane's reduced value goes: value index = g*9 + c
+    const int my_idx = reduced_index_of_lane(lane);
+    const int my_g = my_idx / NPART, my_c = my_idx - my_g * NPART;
 
     for (int r = 0; r < rounds; r++) {
         __syncthreads();                                         // previous flush has read s_part / s_slot
         const int mypos = used - 1 - (r * BATCH + tid);          // back to front (backward.cu:466-479)
+        uint32_t qm = 0u;
         if (mypos >= 0) {
             const uint32_t id = point_list[range.x + mypos];
             const float4 a = splat[3 * (size_t)id], b = splat[3 * (size_t)id + 1], c = splat[3 * (size_t)id + 2];
@@ -208,6 +290,12 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             const uint32_t off = __float_as_uint(c.y), lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
             const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
             s_slot[tid] = off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            qm = quadrant_mask(a, b, tile_x0, tile_y0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned long long bm = __ballot((qm >> q) & 1u);
+            if (lane == 0) s_mask[q][wave] = bm;
         }
 #pragma unroll
         for (int w = 0; w < 4; w++)
@@ -216,44 +304,72 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
         __syncthreads();
 
         const int cnt = min(BATCH, used - r * BATCH);
-        for (int j = 0; j < cnt; j++) {
-            const int pos = used - 1 - (r * BATCH + j);          // 0-based position in the tile's list
-            const float4 a = s_a[j], b = s_b[j];
-            float dx, dy, G, alpha;
-            bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
-            hit = hit && (pos < last_contributor);               // backward.cu:486-488
-            if (!__any(hit)) continue;                           // wave-uniform skip
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
-            if (hit) {
-                Tr = Tr / (1.f - alpha);
-                const float dchannel_dcolor = alpha * Tr;
-                const float c0 = b.z, c1 = b.w, c2 = s_c[j];
-                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0;
-                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c1;
-                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c2;
-                float dL_dalpha = (c0 - acc0) * dpx0 + (c1 - acc1) * dpx1 + (c2 - acc2) * dpx2;
-                v0 = dchannel_dcolor * dpx0; v1 = dchannel_dcolor * dpx1; v2 = dchannel_dcolor * dpx2;
-                dL_dalpha *= Tr;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot; // backward.cu:531-534
-                const float dL_dG = b.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * b.x - gdx * a.w;
-                v3 = dL_dG * dG_ddelx * ddelx_dx;
-                v4 = dL_dG * dG_ddely * ddely_dy;
-                v5 = -0.5f * gdx * dx * dL_dG;
-                v6 = -0.5f * gdx * dy * dL_dG;
-                v7 = -0.5f * gdy * dy * dL_dG;
-                v8 = G * dL_dalpha;
+        const int pos0 = used - 1 - r * BATCH;                   // position of batch entry j is pos0 - j
+        // iterator over the batch entries this wave has to look at (scalar state)
+        int chunk = -1;
+        unsigned long long m = 0;
+        bool more = true;
+        while (more) {
+            float v[64];
+#pragma unroll
+            for (int q = 0; q < 64; q++) v[q] = 0.f;
+            int jv = -1;                                         // lane g remembers the batch entry of group slot g
+            bool any_slot = false;
+#pragma unroll
+            for (int g = 0; g < GROUP_G; g++) {
+                while (more) {
+                    while (m == 0 && chunk < 3) {
+                        chunk++;
+                        m = uniform_u64(s_mask[wave][chunk]);
+                        // entries with pos >= wave_last (j <= pos0 - wave_last) are behind every pixel of this wave
+                        const int jmin = pos0 - wave_last + 1 - chunk * 64;
+                        if (jmin >= 64) m = 0; else if (jmin > 0) m &= ~0ull << jmin;
+                    }
+                    if (m == 0) { more = false; break; }
+                    const int j = chunk * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int pos = pos0 - j;                    // 0-based position in the tile's list
+                    const float4 a = s_a[j], b = s_b[j];
+                    float dx, dy, G, alpha;
+                    bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
+                    hit = hit && (pos < last_contributor);       // backward.cu:486-488
+                    if (!__any(hit)) continue;                   // wave-uniform: try the next entry for this slot
+                    if (hit) {
+                        // 1/(1-alpha) once, as a hardware reciprocal (1 ulp; 1-alpha is in [0.01, 1])
+                        const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
+                        Tr = Tr * rinv;
+                        const float dchannel_dcolor = alpha * Tr;
+                        const float c0 = b.z, c1 = b.w, c2 = s_c[j];
+                        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0;
+                        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c1;
+                        acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c2;
+                        float dL_dalpha = (c0 - acc0) * dpx0 + (c1 - acc1) * dpx1 + (c2 - acc2) * dpx2;
+                        v[g * NPART + 0] = dchannel_dcolor * dpx0;
+                        v[g * NPART + 1] = dchannel_dcolor * dpx1;
+                        v[g * NPART + 2] = dchannel_dcolor * dpx2;
+                        dL_dalpha *= Tr;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final * rinv) * bg_dot;     // backward.cu:531-534
+                        const float dL_dG = b.y * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                        const float dG_ddely = -gdy * b.x - gdx * a.w;
+                        v[g * NPART + 3] = dL_dG * dG_ddelx * ddelx_dx;
+                        v[g * NPART + 4] = dL_dG * dG_ddely * ddely_dy;
+                        v[g * NPART + 5] = -0.5f * gdx * dx * dL_dG;
+                        v[g * NPART + 6] = -0.5f * gdx * dy * dL_dG;
+                        v[g * NPART + 7] = -0.5f * gdy * dy * dL_dG;
+                        v[g * NPART + 8] = G * dL_dalpha;
+                    }
+                    if (lane == g) jv = j;
+                    any_slot = true;
+                    break;
+                }
             }
-            v0 = wave_sum_lane63(v0); v1 = wave_sum_lane63(v1); v2 = wave_sum_lane63(v2);
-            v3 = wave_sum_lane63(v3); v4 = wave_sum_lane63(v4); v5 = wave_sum_lane63(v5);
-            v6 = wave_sum_lane63(v6); v7 = wave_sum_lane63(v7); v8 = wave_sum_lane63(v8);
-            if (lane == 63) {
-                float* d = s_part[wave][j];
-                d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3; d[4] = v4; d[5] = v5; d[6] = v6; d[7] = v7; d[8] = v8;
-            }
+            if (!any_slot) break;
+            const float total = transpose_reduce_64(v, lane);
+            const int myj = __shfl(jv, my_g);                    // batch entry of the slot this lane's value belongs to
+            if (my_idx < GROUP_G * NPART && myj >= 0) s_part[wave][myj][my_c] = total;
         }
         __syncthreads();
         if (tid < cnt) {
