@@ -10,6 +10,7 @@
 // streams the codebook through LDS in tiles that every lane reads as a broadcast.
 #include "common.hpp"
 #include <cfloat>
+#include <cstdlib>
 
 namespace c3dgs {
 
@@ -115,6 +116,188 @@ weighted_distance_generic_kernel(int64_t N, int C, int K, const float* __restric
     if (n < N) { out_dist[n] = best; out_idx[n] = (int64_t)besti; }
 }
 
+
+// ---------------------------------------------------------------- MFMA nearest-codeword search (K = 48)
+//
+// s[c][n] = ||c||^2 - 2 x_n.c  (argmin_c s == argmin_c ||x_n - c||^2) on the fp32 matrix cores:
+// v_mfma_f32_32x32x2_f32 with A = 32 codewords x 2 dims (from an LDS tile stored k-major, conflict-free),
+// B = 2 dims x 32 points (pre-scaled by -2, resident in registers for the whole kernel), C initialised with
+// ||c||^2. In the 32x32 accumulator layout a lane owns ONE point (column = lane&31) and 16 codeword rows, so the
+// running (best, second best, index) update is pure per-lane VALU work that overlaps the next MFMAs; the two
+// half-waves are merged once at the end.
+//
+// Exact reference semantics are kept: the winner's distance is recomputed with the reference's k-ordered FMA
+// chain, and a point whose two best candidates are closer than the rounding-error bound of BOTH formulations
+// (margin = 4e-5*(d_best + d_second + 2||x||^2)) is flagged (index -1) and resolved by
+// wd_fixup_kernel with the exact chain over all codewords (lowest index wins ties).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MF_K = 48;
+constexpr int MF_CT = 128;          // codewords per LDS tile
+constexpr int MF_PTS = 64;          // points per wave (two 32-point B operands)
+
+__device__ __forceinline__ void top2_update(float v, int row, float& best, float& second, int& idx)
+{
+    const float hi = fmaxf(v, best);
+    idx = v < best ? row : idx;
+    best = fminf(v, best);
+    second = fminf(second, hi);
+}
+
+__global__ void __launch_bounds__(256)
+wd_mfma48_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather,
+                 const float* __restrict__ codebook, float* __restrict__ out_dist, int64_t* __restrict__ out_idx)
+{
+    __shared__ float s_cb[2][MF_K][MF_CT];   // k-major tile: lane i reads s_cb[k][i] (consecutive banks)
+    __shared__ float s_norm[2][MF_CT];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t n_base = ((int64_t)blockIdx.x * 4 + wave) * MF_PTS;
+
+    // B operands: b[g][t] = -2 * x[n_base + 32g + i][2t + h]
+    float b[2][MF_K / 2];
+    float xnorm[2];
+    int64_t rows[2];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const int64_t n = n_base + 32 * g + i;
+        const int64_t row = n < N ? (gather ? gather[n] : n) : 0;
+        rows[g] = row;
+        const float2* src = reinterpret_cast<const float2*>(coefs + row * MF_K);
+        float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < MF_K / 2; t++) {
+            const float2 v = src[t];
+            b[g][t] = -2.0f * (h ? v.y : v.x);
+            part = fmaf(v.x, v.x, part);
+            part = fmaf(v.y, v.y, part);
+        }
+        xnorm[g] = part;
+    }
+    float best[2] = { FLT_MAX, FLT_MAX }, second[2] = { FLT_MAX, FLT_MAX };
+    int idx[2] = { 0, 0 };
+
+    const int ntiles = (C + MF_CT - 1) / MF_CT;
+    auto stage = [&](int tile, int buf) {
+        // one codeword per thread pair: thread t stages codeword (t & 127), dims [24*(t>>7), 24*(t>>7)+24)
+        const int c = tid & (MF_CT - 1), half = tid >> 7;
+        const int cg = tile * MF_CT + c;
+        const float4* src = reinterpret_cast<const float4*>(codebook + (size_t)(cg < C ? cg : 0) * MF_K + 24 * half);
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            float4 v = src[q];
+            if (cg >= C) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int k = 24 * half + 4 * q;
+            s_cb[buf][k][c] = v.x; s_cb[buf][k + 1][c] = v.y; s_cb[buf][k + 2][c] = v.z; s_cb[buf][k + 3][c] = v.w;
+        }
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; tile++) {
+        const int buf = tile & 1;
+        if (tid < MF_CT) {          // ||c||^2 of this tile (rows past C get +inf-like so they never win)
+            float nr = 0.f;
+#pragma unroll
+            for (int k = 0; k < MF_K; k++) nr = fmaf(s_cb[buf][k][tid], s_cb[buf][k][tid], nr);
+            s_norm[buf][tid] = (tile * MF_CT + tid < C) ? nr : 3.0e38f;
+        }
+        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
+        __syncthreads();
+#pragma unroll 1
+        for (int sub = 0; sub < MF_CT / 32; sub++) {
+            if (tile * MF_CT + sub * 32 >= C) break;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float nv = s_norm[buf][sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+                acc0[r] = nv; acc1[r] = nv;
+            }
+#pragma unroll
+            for (int t = 0; t < MF_K / 2; t++) {
+                const float a = s_cb[buf][2 * t + h][sub * 32 + i];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[0][t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[1][t], acc1, 0, 0, 0);
+            }
+            const int row0 = tile * MF_CT + sub * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                top2_update(acc0[r], row, best[0], second[0], idx[0]);
+                top2_update(acc1[r], row, best[1], second[1], idx[1]);
+            }
+        }
+        __syncthreads();
+    }
+    // merge the two half-waves (same point in lanes l and l^32), decide, recompute the exact distance
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const float ob = __shfl_xor(best[g], 32), os = __shfl_xor(second[g], 32);
+        const int oi = __shfl_xor(idx[g], 32);
+        const float nb = fminf(best[g], ob);
+        const float ns = fminf(fminf(second[g], os), fmaxf(best[g], ob));
+        const int ni = (ob < best[g] || (ob == best[g] && oi < idx[g])) ? oi : idx[g];
+        const int64_t n = n_base + 32 * g + i;
+        if (h == 0 && n < N) {
+            const float db = nb + xnorm[g], ds = ns + xnorm[g];
+            const float margin = 4e-5f * (fabsf(db) + fabsf(ds) + 2.0f * xnorm[g]) + 1e-37f;
+            const bool ambiguous = !(ns - nb > margin);
+            const float* x = coefs + rows[g] * MF_K;
+            const float* cb = codebook + (size_t)ni * MF_K;
+            float r = 0.f;
+#pragma unroll
+            for (int k = 0; k < MF_K; k++) {
+                const float d = x[k] - cb[k];
+                r = fmaf(d, d, r);
+            }
+            out_dist[n] = r;
+            out_idx[n] = ambiguous ? (int64_t)-1 : (int64_t)ni;
+        }
+    }
+}
+
+// exact re-scan of the flagged points: one wave per flagged point, 64 lanes split the codewords, k-ordered FMA
+// chain per codeword, then a wave argmin that prefers the lower index on ties (== the sequential strict '<').
+template <int K>
+__global__ void __launch_bounds__(256)
+wd_fixup_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather,
+                const float* __restrict__ codebook, float* __restrict__ out_dist, int64_t* __restrict__ out_idx)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t n0 = wave_id * 64;
+    if (n0 >= N) return;
+    const int64_t n = n0 + lane;
+    const bool flagged = n < N && out_idx[n] < 0;
+    unsigned long long m = __ballot(flagged);
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const int64_t np = n0 + l;
+        const int64_t row = gather ? gather[np] : np;
+        const float* x = coefs + row * K;
+        float best = FLT_MAX;
+        int besti = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            const float* cb = codebook + (size_t)c * K;
+            float r = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const float d = x[k] - cb[k];
+                r = fmaf(d, d, r);
+            }
+            if (r < best) { best = r; besti = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(besti, o);
+            if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (lane == 0) { out_dist[np] = best; out_idx[np] = (int64_t)(besti == 0x7fffffff ? 0 : besti); }
+    }
+}
+
 int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const int64_t* gather, const float* codebook,
                              float* out_dist, int64_t* out_idx, hipStream_t s)
 {
@@ -123,7 +306,13 @@ int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const 
     const unsigned grid = (unsigned)((N + per_block - 1) / per_block);
     const bool al16 = (((uintptr_t)coefs | (uintptr_t)codebook) & 15) == 0;
     const bool al8 = (((uintptr_t)coefs | (uintptr_t)codebook) & 7) == 0;
-    if (K == 48 && al16) weighted_distance_kernel<48, 128><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
+    static const bool force_exact = getenv("C3DGS_VQ_EXACT_VALU") != nullptr;   // A/B switch for tests and profiling
+    if (K == 48 && al16 && C >= 32 && !force_exact) {
+        const unsigned g1 = (unsigned)((N + 4 * MF_PTS - 1) / (4 * MF_PTS));
+        wd_mfma48_kernel<<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
+        const unsigned g2 = (unsigned)((N + 255) / 256);
+        wd_fixup_kernel<48><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
+    } else if (K == 48 && al16) weighted_distance_kernel<48, 128><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
     else if (K == 12 && al16) weighted_distance_kernel<12, 512><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
     else if (K == 6 && al8) weighted_distance_kernel<6, 1024><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
     else {
