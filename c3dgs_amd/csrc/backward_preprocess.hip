@@ -19,7 +19,7 @@ struct BwdArgs {
     const float* cov3D_precomp; const int64_t* sh_indices; const int64_t* g_indices;
     const float* view; const float* proj; const float* campos;
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
-    const int32_t* radii; const uint32_t* tiles_touched; const uint32_t* point_offsets; const uint8_t* clamped;
+    const int32_t* radii; const uint32_t* tiles_touched; const uint32_t* inst_offset; const uint8_t* clamped;
     const float* partials;
     c3dgs_raster_grads g;
 };
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
     if (live) {
 
     // ---- (a) sum this Gaussian's per-tile partials: slots [offset_excl, offset_excl + tiles_touched)
-    const uint32_t off0 = (i == 0) ? 0u : a.point_offsets[i - 1];
+    const uint32_t off0 = a.inst_offset[i];
     const uint32_t cntp = a.tiles_touched[i];
     float acc[PARTIAL_FLOATS];
 #pragma unroll
@@ -364,7 +364,7 @@ void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* rad
     a.focal_y = p.H / (2.0f * p.tan_fovy);
     a.focal_x = p.W / (2.0f * p.tan_fovx);
     a.scale_modifier = p.scale_modifier;
-    a.radii = radii; a.tiles_touched = g.tiles_touched; a.point_offsets = g.point_offsets; a.clamped = g.clamped;
+    a.radii = radii; a.tiles_touched = g.tiles_touched; a.inst_offset = g.inst_offset; a.clamped = g.clamped;
     a.partials = partials; a.g = gr;
     const dim3 grid((p.P + 255) / 256), block(256);
     const bool indexed = p.sh_indices != nullptr || p.g_indices != nullptr;

@@ -13,9 +13,9 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 // ---- optional per-stage timing with HIP events recorded on the caller's stream (bench.py's roofline leg).
 // Disabled by default: zero cost. When enabled, every stage launch is bracketed by two events; nothing
 // synchronises until c3dgs_profile_read().
-enum Stage { ST_MARK_VISIBLE, ST_PREPROCESS, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_ZERO_PARTIALS,
+enum Stage { ST_MARK_VISIBLE, ST_PREPROCESS, ST_DEPTH_SORT, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_ZERO_PARTIALS,
              ST_RENDER_BWD, ST_BWD_PREPROCESS, ST_WDIST, ST_VQ_ACC, ST_VQ_APPLY, ST_COUNT };
-static const char* kStageNames[ST_COUNT] = { "mark_visible", "preprocess", "scan", "duplicate_with_keys", "sort",
+static const char* kStageNames[ST_COUNT] = { "mark_visible", "preprocess", "depth_sort", "scan", "duplicate_with_keys", "sort",
                                              "identify_ranges", "render_forward", "zero_partials", "render_backward",
                                              "backward_preprocess", "weighted_distance", "vq_accumulate", "vq_apply" };
 struct ProfRec { int stage; hipEvent_t a, b; };
@@ -109,11 +109,14 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
 
     { StageTimer t_(ST_PREPROCESS, s); launch_preprocess(p, g, radii, s); }          // K2 / K2i
     C3DGS_STAGE("preprocess", p.debug, s);
-    { StageTimer t_(ST_SCAN, s);
-      C3DGS_HIP_TRY(run_inclusive_scan(g.scan_temp, g.scan_temp_bytes, g.tiles_touched, g.point_offsets, P, s)); } // K3
+    { StageTimer t_(ST_DEPTH_SORT, s);                                               // binning stage 1: P Gaussians by depth
+      C3DGS_HIP_TRY(run_depth_sort(g.scan_temp, g.scan_temp_bytes, g.depth_keys, g.depth_keys_sorted, g.ids, g.depth_order, P, s)); }
+    C3DGS_STAGE("depth_sort", p.debug, s);
+    { StageTimer t_(ST_SCAN, s);                                                     // K3, in depth order
+      C3DGS_HIP_TRY(run_scan_in_order(g.scan_temp, g.scan_temp_bytes, g.depth_order, g.tiles_touched, g.sorted_offsets, P, s)); }
     C3DGS_STAGE("scan", p.debug, s);
     uint32_t R_u = 0;                                                                // K4: the one host sync
-    C3DGS_HIP_TRY(hipMemcpyAsync(&R_u, g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    C3DGS_HIP_TRY(hipMemcpyAsync(&R_u, g.sorted_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     C3DGS_HIP_TRY(hipStreamSynchronize(s));
     if (R_u > 0x7fffffffu) return fail(C3DGS_E_INVALID, "num_rendered overflows int32");
     const int R = (int)R_u;
@@ -128,10 +131,10 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     if (R > 0) {
         { StageTimer t_(ST_DUPLICATE, s); launch_duplicate_with_keys(P, g, radii, b, gx, s); } // K5
         C3DGS_STAGE("duplicate_with_keys", p.debug, s);
-        const int end_bit = 32 + (int)higher_msb((uint32_t)T);
+        const int end_bit = (int)higher_msb((uint32_t)T);                           // tile bits only (rasterizer_impl.cu:298)
         { StageTimer t_(ST_SORT, s);
-          C3DGS_HIP_TRY(run_sort_pairs(b.sort_temp, b.sort_temp_bytes, b.keys_unsorted, b.keys_sorted, b.values_unsorted,
-                                       b.point_list, R, end_bit, s)); }              // K6
+          C3DGS_HIP_TRY(run_tile_sort(b.sort_temp, b.sort_temp_bytes, b.keys_unsorted, b.keys_sorted, b.values_unsorted,
+                                      b.point_list, R, end_bit, s)); }               // K6, binning stage 2
         C3DGS_STAGE("sort", p.debug, s);
         { StageTimer t_(ST_RANGES, s); launch_identify_ranges(R, b.keys_sorted, img.ranges, s); } // K8
         C3DGS_STAGE("identify_ranges", p.debug, s);

@@ -40,7 +40,7 @@ inline int fail(int code, const std::string& msg) { set_error(msg); return code;
 // ---------------------------------------------------------------- scratch layouts
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
-size_t scan_temp_bytes(int P);
+size_t scan_temp_bytes(int P);      // max(scan, depth sort) temporary storage for P Gaussians
 size_t sort_temp_bytes(int R, int end_bit);
 
 inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
@@ -61,13 +61,18 @@ inline uint32_t higher_msb(uint32_t n)
 inline void geom_layout(int P, c3dgs_geom_layout* L)
 {
     size_t o = 0, p = (size_t)(P > 0 ? P : 1);
-    L->splat = o;          o = align_up(o + p * SPLAT_F4 * 16);
-    L->depths = o;         o = align_up(o + p * 4);
-    L->tiles_touched = o;  o = align_up(o + p * 4);
-    L->point_offsets = o;  o = align_up(o + p * 4);
-    L->rects = o;          o = align_up(o + p * 8);
-    L->clamped = o;        o = align_up(o + p);
-    L->scan_temp = o;      L->scan_temp_bytes = scan_temp_bytes((int)p);
+    L->splat = o;             o = align_up(o + p * SPLAT_F4 * 16);
+    L->depths = o;            o = align_up(o + p * 4);
+    L->tiles_touched = o;     o = align_up(o + p * 4);
+    L->depth_keys = o;        o = align_up(o + p * 4);
+    L->ids = o;               o = align_up(o + p * 4);
+    L->depth_keys_sorted = o; o = align_up(o + p * 4);
+    L->depth_order = o;       o = align_up(o + p * 4);
+    L->sorted_offsets = o;    o = align_up(o + p * 4);
+    L->inst_offset = o;       o = align_up(o + p * 4);
+    L->rects = o;             o = align_up(o + p * 8);
+    L->clamped = o;           o = align_up(o + p);
+    L->scan_temp = o;         L->scan_temp_bytes = scan_temp_bytes((int)p);
     o = align_up(o + L->scan_temp_bytes);
     L->total_bytes = o;
 }
@@ -75,10 +80,10 @@ inline void geom_layout(int P, c3dgs_geom_layout* L)
 inline void binning_layout(int R, int W, int H, c3dgs_binning_layout* L)
 {
     size_t o = 0, r = (size_t)(R > 0 ? R : 1);
-    int end_bit = 32 + (int)higher_msb((uint32_t)(tiles_x(W) * tiles_y(H)));
-    L->keys_unsorted = o;   o = align_up(o + r * 8);
+    int end_bit = (int)higher_msb((uint32_t)(tiles_x(W) * tiles_y(H)));
+    L->keys_unsorted = o;   o = align_up(o + r * 2);
     L->values_unsorted = o; o = align_up(o + r * 4);
-    L->keys_sorted = o;     o = align_up(o + r * 8);
+    L->keys_sorted = o;     o = align_up(o + r * 2);
     L->point_list = o;      o = align_up(o + r * 4);
     L->sort_temp = o;       L->sort_temp_bytes = sort_temp_bytes((int)r, end_bit);
     o = align_up(o + L->sort_temp_bytes);
@@ -97,11 +102,12 @@ inline void image_layout(int W, int H, c3dgs_image_layout* L)
 
 // ---------------------------------------------------------------- kernel launchers (one per .hip file)
 struct GeomPtrs {
-    float4* splat; float* depths; uint32_t* tiles_touched; uint32_t* point_offsets; uint16_t* rects;
+    float4* splat; float* depths; uint32_t* tiles_touched; uint32_t* depth_keys; uint32_t* ids; uint32_t* depth_keys_sorted;
+    uint32_t* depth_order; uint32_t* sorted_offsets; uint32_t* inst_offset; uint16_t* rects;
     uint8_t* clamped; void* scan_temp; size_t scan_temp_bytes;
 };
 struct BinPtrs {
-    uint64_t* keys_unsorted; uint32_t* values_unsorted; uint64_t* keys_sorted; uint32_t* point_list;
+    uint16_t* keys_unsorted; uint32_t* values_unsorted; uint16_t* keys_sorted; uint32_t* point_list;
     void* sort_temp; size_t sort_temp_bytes;
 };
 struct ImgPtrs { float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_used; };
@@ -110,15 +116,16 @@ inline GeomPtrs geom_ptrs(void* base, int P)
 {
     c3dgs_geom_layout L; geom_layout(P, &L);
     char* b = (char*)base;
-    return { (float4*)(b + L.splat), (float*)(b + L.depths), (uint32_t*)(b + L.tiles_touched),
-             (uint32_t*)(b + L.point_offsets), (uint16_t*)(b + L.rects), (uint8_t*)(b + L.clamped),
-             (void*)(b + L.scan_temp), L.scan_temp_bytes };
+    return { (float4*)(b + L.splat), (float*)(b + L.depths), (uint32_t*)(b + L.tiles_touched), (uint32_t*)(b + L.depth_keys),
+             (uint32_t*)(b + L.ids), (uint32_t*)(b + L.depth_keys_sorted), (uint32_t*)(b + L.depth_order),
+             (uint32_t*)(b + L.sorted_offsets), (uint32_t*)(b + L.inst_offset), (uint16_t*)(b + L.rects),
+             (uint8_t*)(b + L.clamped), (void*)(b + L.scan_temp), L.scan_temp_bytes };
 }
 inline BinPtrs bin_ptrs(void* base, int R, int W, int H)
 {
     c3dgs_binning_layout L; binning_layout(R, W, H, &L);
     char* b = (char*)base;
-    return { (uint64_t*)(b + L.keys_unsorted), (uint32_t*)(b + L.values_unsorted), (uint64_t*)(b + L.keys_sorted),
+    return { (uint16_t*)(b + L.keys_unsorted), (uint32_t*)(b + L.values_unsorted), (uint16_t*)(b + L.keys_sorted),
              (uint32_t*)(b + L.point_list), (void*)(b + L.sort_temp), L.sort_temp_bytes };
 }
 inline ImgPtrs img_ptrs(void* base, int W, int H)
@@ -132,11 +139,14 @@ inline ImgPtrs img_ptrs(void* base, int W, int H)
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, hipStream_t s);
 void launch_duplicate_with_keys(int P, const GeomPtrs& g, const int32_t* radii, const BinPtrs& b, int grid_x, hipStream_t s);
-void launch_identify_ranges(int R, const uint64_t* keys_sorted, uint2* ranges, hipStream_t s);
+void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, hipStream_t s);
 // binning.hip
-hipError_t run_inclusive_scan(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, int P, hipStream_t s);
-hipError_t run_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
-                          uint32_t* vout, int R, int end_bit, hipStream_t s);
+hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
+                          uint32_t* vout, int P, hipStream_t s);
+hipError_t run_scan_in_order(void* temp, size_t temp_bytes, const uint32_t* order, const uint32_t* tiles_touched,
+                             uint32_t* out, int P, hipStream_t s);
+hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin,
+                         uint32_t* vout, int R, int end_bit, hipStream_t s);
 // render.hip
 void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                            const float* colors_precomp, const float* bg, float* out_color, hipStream_t s);

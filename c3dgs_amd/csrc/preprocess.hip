@@ -72,6 +72,7 @@ struct PreArgs {
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     int prefiltered, clamp_color;
     int32_t* radii; float4* splat; float* depths; uint32_t* tiles_touched; uint16_t* rects; uint8_t* clamped;
+    uint32_t* depth_keys; uint32_t* ids;
 };
 
 template <int DEG>
@@ -82,6 +83,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
 
     int32_t out_radius = 0;
     uint32_t out_tiles = 0;
+    uint32_t out_key = 0xffffffffu;            // culled Gaussians sort behind every visible one
     do {
         const f3 p = { a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2] };
         const f3 p_view = xform4x3(p, a.view);
@@ -157,6 +159,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
 
         out_radius = (int32_t)my_radius;
         out_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
+        out_key = __float_as_uint(p_view.z);
         a.depths[i] = p_view.z;
         a.clamped[i] = clamp_bits;
         uint16_t* rc = a.rects + 4 * (size_t)i;
@@ -170,6 +173,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
 
     a.radii[i] = out_radius;
     a.tiles_touched[i] = out_tiles;
+    a.depth_keys[i] = out_key;
+    a.ids[i] = (uint32_t)i;
 }
 
 void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, hipStream_t s)
@@ -186,7 +191,7 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
     a.focal_x = p.W / (2.0f * p.tan_fovx);
     a.scale_modifier = p.scale_modifier; a.prefiltered = p.prefiltered; a.clamp_color = p.clamp_color;
     a.radii = radii; a.splat = g.splat; a.depths = g.depths; a.tiles_touched = g.tiles_touched; a.rects = g.rects;
-    a.clamped = g.clamped;
+    a.clamped = g.clamped; a.depth_keys = g.depth_keys; a.ids = g.ids;
     const dim3 grid((p.P + 255) / 256), block(256);
     const int deg = p.colors_precomp ? 0 : p.D;
     switch (deg) {
@@ -197,28 +202,28 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
     }
 }
 
-// ---- K5: one (key, value) pair per Gaussian x tile, reference rasterizer_impl.cu:70-111.
-// Also stamps the exclusive instance offset into the splat record (word 9).
+// ---- K5: one (tile, Gaussian) pair per Gaussian x tile, reference rasterizer_impl.cu:70-111, walked in
+// (depth, id) order (binning.hip explains why). Thread k handles the k-th nearest Gaussian. Also stamps the
+// exclusive instance offset into the splat record (word 9) and into inst_offset[id] for the backward.
 __global__ void __launch_bounds__(256)
-duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ offsets,
-                           const uint16_t* __restrict__ rects, const float* __restrict__ depths, float4* __restrict__ splat,
-                           uint64_t* __restrict__ keys, uint32_t* __restrict__ values, int grid_x)
+duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
+                           const uint32_t* __restrict__ sorted_offsets, const uint16_t* __restrict__ rects,
+                           float4* __restrict__ splat, uint32_t* __restrict__ inst_offset, uint16_t* __restrict__ keys,
+                           uint32_t* __restrict__ values, int grid_x)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    if (tiles_touched[i] == 0) return;           // == reference's radii[idx] > 0
-    uint32_t off = (i == 0) ? 0u : offsets[i - 1];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= P) return;
+    const uint32_t i = order[k];
+    if (tiles_touched[i] == 0) return;           // == reference's radii[idx] > 0 (culled ones sort last)
+    uint32_t off = (k == 0) ? 0u : sorted_offsets[k - 1];
     reinterpret_cast<float*>(splat + 3 * (size_t)i + 2)[1] = __uint_as_float(off);
+    inst_offset[i] = off;
     const uint2 rc = *reinterpret_cast<const uint2*>(rects + 4 * (size_t)i);
     const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
-    const uint64_t dbits = (uint64_t)__float_as_uint(depths[i]);
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
-            uint64_t key = (uint64_t)(uint32_t)(y * grid_x + x);
-            key <<= 32;
-            key |= dbits;
-            keys[off] = key;
-            values[off] = (uint32_t)i;
+            keys[off] = (uint16_t)(y * grid_x + x);
+            values[off] = i;
             off++;
         }
 }
@@ -226,20 +231,20 @@ duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ tiles_touched, co
 void launch_duplicate_with_keys(int P, const GeomPtrs& g, const int32_t* /*radii*/, const BinPtrs& b, int grid_x, hipStream_t s)
 {
     if (P <= 0) return;
-    duplicate_with_keys_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.tiles_touched, g.point_offsets, g.rects, g.depths,
-                                                               g.splat, b.keys_unsorted, b.values_unsorted, grid_x);
+    duplicate_with_keys_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.depth_order, g.tiles_touched, g.sorted_offsets, g.rects,
+                                                               g.splat, g.inst_offset, b.keys_unsorted, b.values_unsorted, grid_x);
 }
 
 // ---- K8: reference rasterizer_impl.cu:116-138 (ranges pre-zeroed by the caller, :308)
 __global__ void __launch_bounds__(256)
-identify_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
+identify_ranges_kernel(int L, const uint16_t* __restrict__ keys, uint2* __restrict__ ranges)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= L) return;
-    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    const uint32_t cur = keys[idx];
     if (idx == 0) ranges[cur].x = 0;
     else {
-        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        const uint32_t prev = keys[idx - 1];
         if (cur != prev) {
             ranges[prev].y = (uint32_t)idx;
             ranges[cur].x = (uint32_t)idx;
@@ -248,7 +253,7 @@ identify_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restri
     if (idx == L - 1) ranges[cur].y = (uint32_t)L;
 }
 
-void launch_identify_ranges(int R, const uint64_t* keys_sorted, uint2* ranges, hipStream_t s)
+void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, hipStream_t s)
 {
     if (R <= 0) return;
     identify_ranges_kernel<<<(R + 255) / 256, 256, 0, s>>>(R, keys_sorted, ranges);

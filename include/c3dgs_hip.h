@@ -145,22 +145,27 @@ int c3dgs_vq_apply(int32_t K, int32_t D, const float* S, float* codebook, float*
 /* ---- introspection (tests and profiling only) ---- */
 typedef struct c3dgs_geom_layout {   /* byte offsets into the geometry buffer for P Gaussians */
     size_t total_bytes;
-    size_t splat;          /* float4[3*P]: {x, y, conic_a, conic_b} {conic_c, opacity, r, g} {b, bits(offset_excl), bits(rect_lo), bits(rect_hi)} */
+    size_t splat;          /* float4[3*P]: {x, y, conic_a, conic_b} {conic_c, opacity, r, g} {b, bits(instance offset), bits(rect_lo), bits(rect_hi)} */
     size_t depths;         /* float[P]                                                     */
     size_t tiles_touched;  /* uint32[P]                                                    */
-    size_t point_offsets;  /* uint32[P] inclusive scan                                     */
+    size_t depth_keys;     /* uint32[P] depth bits, 0xFFFFFFFF for culled Gaussians        */
+    size_t ids;            /* uint32[P] 0..P-1 (sort payload in)                           */
+    size_t depth_keys_sorted; /* uint32[P]                                                 */
+    size_t depth_order;    /* uint32[P] Gaussian ids in (depth, id) order                  */
+    size_t sorted_offsets; /* uint32[P] inclusive scan of tiles_touched in depth order     */
+    size_t inst_offset;    /* uint32[P] exclusive instance offset of each Gaussian id      */
     size_t rects;          /* uint16[4*P]: xmin, ymin, xmax, ymax (tile units)             */
     size_t clamped;        /* uint8[P] bit c set = channel c was clamped                   */
-    size_t scan_temp;      /* rocPRIM scan temporary storage                               */
+    size_t scan_temp;      /* rocPRIM scan / depth-sort temporary storage                  */
     size_t scan_temp_bytes;
 } c3dgs_geom_layout;
 
 typedef struct c3dgs_binning_layout { /* byte offsets into the binning buffer for R instances */
     size_t total_bytes;
-    size_t keys_unsorted;   /* uint64[R]                                                   */
-    size_t values_unsorted; /* uint32[R]                                                   */
-    size_t keys_sorted;     /* uint64[R]                                                   */
-    size_t point_list;      /* uint32[R] sorted Gaussian ids                               */
+    size_t keys_unsorted;   /* uint16[R] tile id, emitted in (depth, id) order of the Gaussians */
+    size_t values_unsorted; /* uint32[R] Gaussian id                                       */
+    size_t keys_sorted;     /* uint16[R] tile id after the stable tile sort                */
+    size_t point_list;      /* uint32[R] Gaussian ids sorted by (tile, depth, id)          */
     size_t sort_temp;
     size_t sort_temp_bytes;
 } c3dgs_binning_layout;

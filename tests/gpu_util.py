@@ -84,17 +84,22 @@ def unpack(fw):
         out["rgb"] = np.stack([splat[:, 6], splat[:, 7], splat[:, 8]], 1)
         out["depths"] = _view(geom, gl.depths, P, torch.float32).cpu().numpy()
         out["tiles_touched"] = _view(geom, gl.tiles_touched, P, torch.int32).cpu().numpy().view(np.uint32)
-        out["point_offsets"] = _view(geom, gl.point_offsets, P, torch.int32).cpu().numpy().view(np.uint32)
+        out["depth_order"] = _view(geom, gl.depth_order, P, torch.int32).cpu().numpy().view(np.uint32)
+        out["inst_offset"] = _view(geom, gl.inst_offset, P, torch.int32).cpu().numpy().view(np.uint32)
         cl = _view(geom, gl.clamped, P, torch.uint8).cpu().numpy()
         out["clamped"] = np.stack([(cl >> c) & 1 for c in range(3)], 1).astype(np.uint8)
     if R > 0:
         bl = _lib.BinningLayout()
         L.c3dgs_get_binning_layout(R, W, H, C.byref(bl))
         b = fw["binning"]
-        out["keys_unsorted"] = _view(b, bl.keys_unsorted, R, torch.int64).cpu().numpy().view(np.uint64)
+        # the library keeps 16-bit tile keys; the reference's 64-bit key is (tile << 32) | depth bits of the Gaussian
+        dbits = out["depths"].view(np.uint32).astype(np.uint64)
+        tk_u = _view(b, bl.keys_unsorted, R, torch.int16).cpu().numpy().view(np.uint16).astype(np.uint64)
+        tk_s = _view(b, bl.keys_sorted, R, torch.int16).cpu().numpy().view(np.uint16).astype(np.uint64)
         out["values_unsorted"] = _view(b, bl.values_unsorted, R, torch.int32).cpu().numpy().view(np.uint32)
-        out["keys_sorted"] = _view(b, bl.keys_sorted, R, torch.int64).cpu().numpy().view(np.uint64)
         out["point_list"] = _view(b, bl.point_list, R, torch.int32).cpu().numpy().view(np.uint32)
+        out["keys_unsorted"] = (tk_u << np.uint64(32)) | dbits[out["values_unsorted"]]
+        out["keys_sorted"] = (tk_s << np.uint64(32)) | dbits[out["point_list"]]
     return out
 
 

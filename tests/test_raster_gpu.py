@@ -20,7 +20,10 @@ def _check_forward(hipo, st):
     np.testing.assert_array_equal(hipo["radii"], st.radii)
     if st.P > 0:
         np.testing.assert_array_equal(hipo["tiles_touched"], st.tiles_touched)
-        np.testing.assert_array_equal(hipo["point_offsets"], st.point_offsets)
+        # binning stage 1: Gaussians in (depth bits, id) order, culled ones last
+        vis_ids = np.nonzero(st.radii > 0)[0]
+        want = vis_ids[np.lexsort((vis_ids, st.depths[vis_ids].view(np.uint32)))]
+        np.testing.assert_array_equal(hipo["depth_order"][:len(want)], want.astype(np.uint32))
         vis = st.radii > 0
         # per-Gaussian floats feeding the keys: bit-exact (same fp32 op order, no contraction)
         np.testing.assert_array_equal(hipo["depths"][vis].view(np.uint32), st.depths[vis].view(np.uint32))
@@ -30,8 +33,12 @@ def _check_forward(hipo, st):
         if st.inputs["colors_precomp"] is None:
             np.testing.assert_array_equal(hipo["rgb"][vis].view(np.uint32), st.rgb[vis].view(np.uint32))
     if st.num_rendered > 0:
-        np.testing.assert_array_equal(hipo["keys_unsorted"], st.keys_unsorted)
-        np.testing.assert_array_equal(hipo["values_unsorted"], st.values_unsorted)
+        # same (key, value) pairs as the reference emits (emission ORDER is depth-major here: binning.hip) ...
+        a = np.lexsort((hipo["values_unsorted"], hipo["keys_unsorted"]))
+        b = np.lexsort((st.values_unsorted, st.keys_unsorted))
+        np.testing.assert_array_equal(hipo["keys_unsorted"][a], st.keys_unsorted[b])
+        np.testing.assert_array_equal(hipo["values_unsorted"][a], st.values_unsorted[b])
+        # ... and bit-identical sorted keys and sorted point list
         np.testing.assert_array_equal(hipo["keys_sorted"], st.keys_sorted)
         np.testing.assert_array_equal(hipo["point_list"], st.point_list)
     np.testing.assert_array_equal(hipo["ranges"], st.ranges)
@@ -116,7 +123,7 @@ def test_full_hd_properties(hip):
     ks = u["keys_sorted"]
     assert np.all(ks[1:] >= ks[:-1])
     np.testing.assert_array_equal(np.sort(u["keys_unsorted"]), ks)
-    order = np.argsort(u["keys_unsorted"], kind="stable")
+    order = np.lexsort((u["values_unsorted"], u["keys_unsorted"]))     # (tile, depth, id): ties in id order
     np.testing.assert_array_equal(u["values_unsorted"][order], u["point_list"])
     tiles = (ks >> np.uint64(32)).astype(np.int64)
     rg = u["ranges"].astype(np.int64)
