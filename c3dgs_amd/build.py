@@ -24,7 +24,8 @@ SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "backward_preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
-    "render.hip": [],
+    # SLP packing into v_pk_*_f32 costs register shuffles in the blend loops and keeps DPP adds from fusing
+    "render.hip": os.environ.get("C3DGS_RENDER_FLAGS", "-fno-slp-vectorize").split(),
     "vq.hip": [],
 }
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gsmath.hpp"),

@@ -39,23 +39,38 @@ __device__ __forceinline__ bool gaussian_alpha(float mx, float my, float ca, flo
 }
 
 // Which of the tile's four 8x8 quadrants (= waves) can this Gaussian touch at all?  A pixel only blends the
-// Gaussian if alpha = min(0.99, o*exp(power)) >= 1/255, i.e. 0.5*d^T C d <= tau with tau = ln(255*o); that ellipse
-// has the axis-aligned half extents sqrt(2 tau C^-1_xx), sqrt(2 tau C^-1_yy). Quadrants outside the (slightly
-// inflated: +1e-4 relative, +0.01 px, far above the fp32 error of the per-pixel test) box cannot contain a
-// contributing pixel, so skipping them changes no result. Bit q = qy*2+qx. Anything non-finite -> no culling.
+// Gaussian if alpha = min(0.99, o*exp(power)) >= 1/255, i.e. f(d) = 0.5*d^T C d <= tau with tau = ln(255*o).
+// f is convex, so its minimum over a quadrant's pixel rectangle is 0 if the mean lies inside it and otherwise sits
+// on one of the four edges, where it is a clamped 1-D parabola minimum. A quadrant whose minimum exceeds tau
+// (inflated by 1e-4 relative + 1e-4 absolute and 0.01 px of rectangle slack, far above the fp32 error of the
+// per-pixel test) contains no contributing pixel, so skipping it changes no result. Bit q = qy*2+qx.
+// Anything non-finite or non-positive-definite -> no culling.
+__device__ __forceinline__ float min_power_on_rect(float ca, float cb, float cc, float nb_c, float nb_a,
+                                                   float dx0, float dx1, float dy0, float dy1)
+{
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return 0.f;
+    auto f = [&](float dx, float dy) { return 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy; };
+    const float ya = fminf(fmaxf(nb_c * dx0, dy0), dy1), yb = fminf(fmaxf(nb_c * dx1, dy0), dy1);
+    const float xa = fminf(fmaxf(nb_a * dy0, dx0), dx1), xb = fminf(fmaxf(nb_a * dy1, dx0), dx1);
+    return fminf(fminf(f(dx0, ya), f(dx1, yb)), fminf(f(xa, dy0), f(xb, dy1)));
+}
+
 __device__ __forceinline__ uint32_t quadrant_mask(const float4 a, const float4 b, float tile_x0, float tile_y0)
 {
     const float mx = a.x, my = a.y, ca = a.z, cb = a.w, cc = b.x, op = b.y;
     if (op < (1.0f / 255.0f) * 0.999f) return 0u;          // alpha <= o < 1/255 everywhere
     const float det = ca * cc - cb * cb;
-    const float tau2 = 2.0f * __logf(255.0f * op) * 1.0001f + 2e-4f;
-    const float ex = sqrtf(tau2 * cc / det) * 1.0001f + 0.01f;
-    const float ey = sqrtf(tau2 * ca / det) * 1.0001f + 0.01f;
-    if (!(det > 0.0f) || !(ex < 1e30f) || !(ey < 1e30f)) return 0xfu;
-    const float lx = mx - ex, hx = mx + ex, ly = my - ey, hy = my + ey;
-    const bool x0 = hx >= tile_x0 && lx <= tile_x0 + 7.0f, x1 = hx >= tile_x0 + 8.0f && lx <= tile_x0 + 15.0f;
-    const bool y0 = hy >= tile_y0 && ly <= tile_y0 + 7.0f, y1 = hy >= tile_y0 + 8.0f && ly <= tile_y0 + 15.0f;
-    return (uint32_t)(x0 && y0) | ((uint32_t)(x1 && y0) << 1) | ((uint32_t)(x0 && y1) << 2) | ((uint32_t)(x1 && y1) << 3);
+    const float tau = __logf(255.0f * op) * 1.0001f + 1e-4f;
+    if (!(det > 0.0f) || !(ca > 0.0f) || !(cc > 0.0f) || !(tau < 1e30f)) return 0xfu;
+    const float nb_c = -cb / cc, nb_a = -cb / ca;           // argmin of f along a vertical / horizontal line
+    uint32_t mask = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float x0 = tile_x0 + (float)((q & 1) * 8) - 0.01f - mx, y0 = tile_y0 + (float)((q >> 1) * 8) - 0.01f - my;
+        const float fmin = min_power_on_rect(ca, cb, cc, nb_c, nb_a, x0, x0 + 7.02f, y0, y0 + 7.02f);
+        mask |= (uint32_t)(!(fmin > tau)) << q;              // NaN -> keep
+    }
+    return mask;
 }
 
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
@@ -275,6 +290,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     int wave_last = last_contributor;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, o));
+    wave_last = __builtin_amdgcn_readfirstlane(wave_last);      // tell the compiler it is wave-uniform (scalar loop control)
     // where this lane's reduced value goes: value index = g*9 + c
     const int my_idx = reduced_index_of_lane(lane);
     const int my_g = my_idx / NPART, my_c = my_idx - my_g * NPART;
