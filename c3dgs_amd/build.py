@@ -22,7 +22,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno
 SOURCES = {
     "c_abi.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
-    "backward_preprocess.hip": ["-ffp-contract=off"],
+    "backward_preprocess.hip": ["-ffp-contract=off"] + os.environ.get("C3DGS_BWDPRE_FLAGS", "").split(),
     "binning.hip": [],
     # SLP packing into v_pk_*_f32 costs register shuffles in the blend loops and keeps DPP adds from fusing
     "render.hip": os.environ.get("C3DGS_RENDER_FLAGS", "-fno-slp-vectorize").split(),

@@ -11,6 +11,13 @@
 #include "common.hpp"
 #include "gsmath.hpp"
 
+#ifndef C3DGS_ABLATE_SH
+#define C3DGS_ABLATE_SH 0   // timing experiments only
+#endif
+#ifndef C3DGS_ABLATE_GS
+#define C3DGS_ABLATE_GS 0
+#endif
+
 namespace c3dgs {
 
 struct BwdArgs {
@@ -19,8 +26,8 @@ struct BwdArgs {
     const float* cov3D_precomp; const int64_t* sh_indices; const int64_t* g_indices;
     const float* view; const float* proj; const float* campos;
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
-    const int32_t* radii; const uint32_t* tiles_touched; const uint32_t* inst_offset; const uint8_t* clamped;
-    const float* partials;
+    const int32_t* radii; const uint32_t* tiles_touched; const uint32_t* inst_offset; const uint8_t* clamped; const float4* splat;
+    const float* partials; const uint8_t* touched;
     c3dgs_raster_grads g;
 };
 
@@ -121,6 +128,49 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
     if (INDEXED) { s_row[threadIdx.x] = -1; s_gi[threadIdx.x] = -1; }
 
     const bool live = i < a.P && a.radii[i] > 0;
+
+    // ---- (a) sum each Gaussian's per-tile partials: slots [start, end) of inst_offset (id order, so the 64
+    // Gaussians of a wave own ONE contiguous slot range). A per-lane loop over global memory would run as long as
+    // the wave's largest Gaussian and pay a dependent HBM latency per slot; instead the wave streams its range
+    // through LDS in chunks with coalesced, independent loads (skipping never-written slots by their flag byte)
+    // and every lane then adds up its own run from LDS. Fixed order -> still bitwise reproducible.
+    constexpr int CH = 128;
+    __shared__ float s_stage[4][CH][PARTIAL_FLOATS];
+    float acc[PARTIAL_FLOATS];
+#pragma unroll
+    for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] = 0.f;
+    {
+        const int lane_ = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int ic = min(i, a.P - 1);                       // lanes past P clamp to the last Gaussian (empty run)
+        const uint32_t end_ = a.inst_offset[ic];
+        uint32_t start_ = (ic == 0) ? 0u : a.inst_offset[ic - 1];
+        if (i >= a.P) start_ = end_;
+        const uint32_t w_begin = __builtin_amdgcn_readfirstlane(start_);
+        const uint32_t w_end = __builtin_amdgcn_readlane(end_, 63);
+        for (uint32_t c0 = w_begin; c0 < w_end; c0 += CH) {
+            const uint32_t n = min((uint32_t)CH, w_end - c0);
+#pragma unroll
+            for (int k = 0; k < CH / 64; k++) {
+                const uint32_t sl = (uint32_t)(k * 64 + lane_);
+                if (sl < n) {
+                    const bool wr = a.touched[c0 + sl] != 0;
+                    const float* src = a.partials + (size_t)(c0 + sl) * PARTIAL_FLOATS;
+#pragma unroll
+                    for (int q = 0; q < PARTIAL_FLOATS; q++) s_stage[wv][sl][q] = wr ? src[q] : 0.f;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t lo = max(start_, c0), hi = min(end_, c0 + n);
+            for (uint32_t sl = lo; sl < hi; sl++) {
+#pragma unroll
+                for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] += s_stage[wv][sl - c0][q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     if (i < a.P && !live) {                // culled: the reference leaves its zero-filled rows untouched
         if (o.dL_dmeans2D) { o.dL_dmeans2D[3 * si] = 0.f; o.dL_dmeans2D[3 * si + 1] = 0.f; o.dL_dmeans2D[3 * si + 2] = 0.f; }
         if (o.dL_dcolors) { o.dL_dcolors[3 * si] = 0.f; o.dL_dcolors[3 * si + 1] = 0.f; o.dL_dcolors[3 * si + 2] = 0.f; }
@@ -136,20 +186,15 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
     }
     if (live) {
 
-    // ---- (a) sum this Gaussian's per-tile partials: slots [offset_excl, offset_excl + tiles_touched)
-    const uint32_t off0 = a.inst_offset[i];
-    const uint32_t cntp = a.tiles_touched[i];
-    float acc[PARTIAL_FLOATS];
-#pragma unroll
-    for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] = 0.f;
-    for (uint32_t s = 0; s < cntp; s++) {
-        const float* src = a.partials + (size_t)(off0 + s) * PARTIAL_FLOATS;
-#pragma unroll
-        for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] += src[q];
-    }
+    // acc = {sum alpha*T*dL_dpix (3), S0, Sx, Sy, Sxx, Sxy, Syy}: moments of w = G*dL_dalpha about the 2D mean
+    // (render.hip). The reference's per-pair products (backward.cu:538-554) are linear in them:
+    const float4 rec0 = a.splat[3 * si], rec1 = a.splat[3 * si + 1];
+    const float k_a = rec0.z, k_b = rec0.w, k_c = rec1.x, opac = rec1.y;
     const float dcol[3] = { acc[0], acc[1], acc[2] };
-    const float d2x = acc[3], d2y = acc[4];
-    const float dcon_x = acc[5], dcon_y = acc[6], dcon_w = acc[7];
+    const float d2x = -0.5f * (float)a.W * opac * (k_a * acc[4] + k_b * acc[5]);
+    const float d2y = -0.5f * (float)a.H * opac * (k_c * acc[5] + k_b * acc[4]);
+    const float dcon_x = -0.5f * opac * acc[6], dcon_y = -0.5f * opac * acc[7], dcon_w = -0.5f * opac * acc[8];
+    acc[8] = acc[3];                       // dL_dopacity = sum G*dL_dalpha
     if (o.dL_dcolors) { o.dL_dcolors[3 * si] = dcol[0]; o.dL_dcolors[3 * si + 1] = dcol[1]; o.dL_dcolors[3 * si + 2] = dcol[2]; }
     if (o.dL_dmeans2D) { o.dL_dmeans2D[3 * si] = d2x; o.dL_dmeans2D[3 * si + 1] = d2y; o.dL_dmeans2D[3 * si + 2] = 0.f; }
     if (o.dL_dopacity) o.dL_dopacity[si] = acc[8];
@@ -323,7 +368,7 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
     if (INDEXED) {
         __syncthreads();
         const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
-        if (o.dL_dsh && a.sh) {
+        if (o.dL_dsh && a.sh && !C3DGS_ABLATE_SH) {
             const int k = lane / 3, ch = lane - 3 * k;
             for (int j = 0; j < 64; j++) {
                 const int64_t row = s_row[wbase + j];            // wave-uniform
@@ -332,7 +377,7 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
                     atomicAdd(o.dL_dsh + (size_t)row * a.M * 3 + lane, s_basis[wbase + j][k] * s_g[wbase + j][ch]);
             }
         }
-        if (a.scales) {
+        if (a.scales && !C3DGS_ABLATE_GS) {
             if (o.dL_dscales)
 #pragma unroll
                 for (int it = 0; it < 3; it++) {
@@ -352,7 +397,7 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
 }
 
 void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* radii, const GeomPtrs& g,
-                                const float* partials, const c3dgs_raster_grads& gr, hipStream_t s)
+                                const float* partials, const uint8_t* touched, const c3dgs_raster_grads& gr, hipStream_t s)
 {
     if (p.P <= 0) return;
     BwdArgs a;
@@ -364,8 +409,8 @@ void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* rad
     a.focal_y = p.H / (2.0f * p.tan_fovy);
     a.focal_x = p.W / (2.0f * p.tan_fovx);
     a.scale_modifier = p.scale_modifier;
-    a.radii = radii; a.tiles_touched = g.tiles_touched; a.inst_offset = g.inst_offset; a.clamped = g.clamped;
-    a.partials = partials; a.g = gr;
+    a.radii = radii; a.tiles_touched = g.tiles_touched; a.inst_offset = g.inst_offset; a.clamped = g.clamped; a.splat = g.splat;
+    a.partials = partials; a.touched = touched; a.g = gr;
     const dim3 grid((p.P + 255) / 256), block(256);
     const bool indexed = p.sh_indices != nullptr || p.g_indices != nullptr;
     const int deg = p.sh ? p.D : 0;

@@ -145,6 +145,7 @@ hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, ui
                           uint32_t* vout, int P, hipStream_t s);
 hipError_t run_scan_in_order(void* temp, size_t temp_bytes, const uint32_t* order, const uint32_t* tiles_touched,
                              uint32_t* out, int P, hipStream_t s);
+hipError_t run_scan_by_id(void* temp, size_t temp_bytes, const uint32_t* tiles_touched, uint32_t* out, int P, hipStream_t s);
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin,
                          uint32_t* vout, int R, int end_bit, hipStream_t s);
 // render.hip
@@ -152,10 +153,10 @@ void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* poi
                            const float* colors_precomp, const float* bg, float* out_color, hipStream_t s);
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                             const float* colors_precomp, const float* bg, const float* dL_dpix, float* partials,
-                            hipStream_t s);
+                            uint8_t* touched, hipStream_t s);
 // backward_preprocess.hip
 void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* radii, const GeomPtrs& g,
-                                const float* partials, const c3dgs_raster_grads& gr, hipStream_t s);
+                                const float* partials, const uint8_t* touched, const c3dgs_raster_grads& gr, hipStream_t s);
 // vq.hip
 int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const int64_t* gather, const float* codebook,
                              float* out_dist, int64_t* out_idx, hipStream_t s);

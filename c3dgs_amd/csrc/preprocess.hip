@@ -204,20 +204,20 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
 
 // ---- K5: one (tile, Gaussian) pair per Gaussian x tile, reference rasterizer_impl.cu:70-111, walked in
 // (depth, id) order (binning.hip explains why). Thread k handles the k-th nearest Gaussian. Also stamps the
-// exclusive instance offset into the splat record (word 9) and into inst_offset[id] for the backward.
+// id-ordered instance slot offset into the splat record (word 9) for the backward.
 __global__ void __launch_bounds__(256)
 duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
                            const uint32_t* __restrict__ sorted_offsets, const uint16_t* __restrict__ rects,
-                           float4* __restrict__ splat, uint32_t* __restrict__ inst_offset, uint16_t* __restrict__ keys,
+                           float4* __restrict__ splat, const uint32_t* __restrict__ inst_offset, uint16_t* __restrict__ keys,
                            uint32_t* __restrict__ values, int grid_x)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= P) return;
     const uint32_t i = order[k];
     if (tiles_touched[i] == 0) return;           // == reference's radii[idx] > 0 (culled ones sort last)
-    uint32_t off = (k == 0) ? 0u : sorted_offsets[k - 1];
-    reinterpret_cast<float*>(splat + 3 * (size_t)i + 2)[1] = __uint_as_float(off);
-    inst_offset[i] = off;
+    uint32_t off = (k == 0) ? 0u : sorted_offsets[k - 1];          // where this Gaussian's pairs go (depth order)
+    const uint32_t slot0 = (i == 0) ? 0u : inst_offset[i - 1];     // where its backward partial sums go (id order)
+    reinterpret_cast<float*>(splat + 3 * (size_t)i + 2)[1] = __uint_as_float(slot0);
     const uint2 rc = *reinterpret_cast<const uint2*>(rects + 4 * (size_t)i);
     const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
     for (int y = y0; y < y1; y++)

@@ -252,7 +252,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                        const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
                        const float* __restrict__ bg, const float* __restrict__ final_Ts,
                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-                       float* __restrict__ partials)
+                       float* __restrict__ partials, uint8_t* __restrict__ touched)
 {
     const int tile = tile_of_block(blockIdx.x, T);
     if (tile >= T || (blockIdx.x >> 3) >= ((T + 7) >> 3)) return;
@@ -284,7 +284,6 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     if (inside) { dpx0 = dL_dpixels[pix]; dpx1 = dL_dpixels[HW + pix]; dpx2 = dL_dpixels[2 * HW + pix]; }
     const float bg_dot = bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;       // backward.cu:460-461
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
     // nothing behind the deepest last_contributor of this wave's 64 pixels can matter to this wave
     int wave_last = last_contributor;
@@ -366,16 +365,17 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                         dL_dalpha *= Tr;
                         last_alpha = alpha;
                         dL_dalpha += (-T_final * rinv) * bg_dot;     // backward.cu:531-534
-                        const float dL_dG = b.y * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                        const float dG_ddely = -gdy * b.x - gdx * a.w;
-                        v[g * NPART + 3] = dL_dG * dG_ddelx * ddelx_dx;
-                        v[g * NPART + 4] = dL_dG * dG_ddely * ddely_dy;
-                        v[g * NPART + 5] = -0.5f * gdx * dx * dL_dG;
-                        v[g * NPART + 6] = -0.5f * gdx * dy * dL_dG;
-                        v[g * NPART + 7] = -0.5f * gdy * dy * dL_dG;
-                        v[g * NPART + 8] = G * dL_dalpha;
+                        // raw moments of w = G*dL_dalpha about the Gaussian's mean; the per-Gaussian linear maps to
+                        // dL_dmean2D / dL_dconic / dL_dopacity (backward.cu:538-554) are applied ONCE per Gaussian,
+                        // after the sum over pixels and tiles, in backward_preprocess.hip
+                        const float w = G * dL_dalpha;
+                        const float wx = w * dx, wy = w * dy;
+                        v[g * NPART + 3] = w;
+                        v[g * NPART + 4] = wx;
+                        v[g * NPART + 5] = wy;
+                        v[g * NPART + 6] = wx * dx;
+                        v[g * NPART + 7] = wx * dy;
+                        v[g * NPART + 8] = wy * dy;
                     }
                     if (lane == g) jv = j;
                     any_slot = true;
@@ -393,18 +393,19 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
 #pragma unroll
             for (int q = 0; q < NPART; q++)
                 dst[q] = (s_part[0][tid][q] + s_part[1][tid][q]) + (s_part[2][tid][q] + s_part[3][tid][q]);
+            touched[s_slot[tid]] = 1;
         }
     }
 }
 
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                             const float* /*colors_precomp*/, const float* bg, const float* dL_dpix, float* partials,
-                            hipStream_t s)
+                            uint8_t* touched, hipStream_t s)
 {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     const int grid = ((T + 7) / 8) * 8;
     render_backward_kernel<<<grid, 256, 0, s>>>(W, H, gx, T, img.ranges, img.tile_used, point_list, splat, bg, img.final_T,
-                                                img.n_contrib, dL_dpix, partials);
+                                                img.n_contrib, dL_dpix, partials, touched);
 }
 
 } // namespace c3dgs

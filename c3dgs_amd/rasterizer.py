@@ -62,18 +62,39 @@ def mat_to_quat(m, normed=True):
     return x, y, z, w, m[0, 3], m[1, 3], m[2, 3]
 
 
+_CAMERA_CACHE = {}
+_CAMERA_CACHE_MAX = 512
+
+
 def camera_matrices(intrinsic, extrinsic_vector, device):
     """(viewmatrix, projmatrix, campos, tanfovx, tanfovy, H, W) exactly as the reference's autograd
-    wrapper assembles them (__init__.py:152-172), computed once on the host in fp32."""
-    intr = intrinsic.detach().cpu()
-    tanfovx = float(math.tan(float(intr[0, 0]) * 0.5))
-    tanfovy = float(math.tan(float(intr[1, 1]) * 0.5))
-    image_height = int(intr[1, 2])
-    image_width = int(intr[0, 2])
-    view = quat_to_mat(extrinsic_vector)
-    proj = view @ getProjectionMatrix(intr)
+    wrapper assembles them (__init__.py:152-172): fp32 matrices built on the host from the pose's VALUES.
+    One device->host transfer per call (the reference does ~10 scalar reads plus a GPU matmul and inverse);
+    the device copies are cached by value, so mark_visible + forward + backward of one view, and every
+    revisit of a training camera, reuse them."""
+    dev = torch.device(device)
+    ev, intr = extrinsic_vector.detach(), intrinsic.detach()
+    if ev.is_cuda and intr.is_cuda and ev.device == intr.device:
+        host = torch.cat([ev.reshape(-1).float(), intr.reshape(-1).float()]).cpu()
+        evh, inh = host[:7], host[7:].reshape(3, 3)
+    else:
+        evh, inh = ev.cpu().float(), intr.cpu().float()
+    key = (tuple(evh.tolist()), tuple(inh.reshape(-1).tolist()), str(dev))
+    hit = _CAMERA_CACHE.get(key)
+    if hit is not None:
+        return hit
+    tanfovx = float(math.tan(float(inh[0, 0]) * 0.5))
+    tanfovy = float(math.tan(float(inh[1, 1]) * 0.5))
+    image_height = int(inh[1, 2])
+    image_width = int(inh[0, 2])
+    view = quat_to_mat(evh)
+    proj = view @ getProjectionMatrix(inh)
     campos = view.inverse()[3, :3].contiguous()
-    return view.to(device), proj.contiguous().to(device), campos.to(device), tanfovx, tanfovy, image_height, image_width
+    out = (view.to(dev), proj.contiguous().to(dev), campos.to(dev), tanfovx, tanfovy, image_height, image_width)
+    if len(_CAMERA_CACHE) >= _CAMERA_CACHE_MAX:
+        _CAMERA_CACHE.pop(next(iter(_CAMERA_CACHE)))
+    _CAMERA_CACHE[key] = out
+    return out
 
 
 def cpu_deep_copy_tuple(input_tuple):
@@ -547,9 +568,8 @@ class GaussianRasterizer(nn.Module):
 
     def markVisible(self, positions, extrinsic_vector):
         with torch.no_grad():
-            view = quat_to_mat(extrinsic_vector)
-            proj = view @ getProjectionMatrix(self.raster_settings.intrinsic.detach().cpu())
-            return _C.mark_visible(positions, view.to(positions.device), proj.to(positions.device))
+            view, proj = camera_matrices(self.raster_settings.intrinsic, extrinsic_vector, positions.device)[:2]
+            return _C.mark_visible(positions, view, proj)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, extrinsic_vector=None, extrinsic=None):
@@ -575,9 +595,8 @@ class GaussianRasterizerIndexed(nn.Module):
 
     def markVisible(self, positions, extrinsic_vector):
         with torch.no_grad():
-            view = quat_to_mat(extrinsic_vector)
-            proj = view @ getProjectionMatrix(self.raster_settings.intrinsic.detach().cpu())
-            return _C.mark_visible(positions, view.to(positions.device), proj.to(positions.device))
+            view, proj = camera_matrices(self.raster_settings.intrinsic, extrinsic_vector, positions.device)[:2]
+            return _C.mark_visible(positions, view, proj)
 
     def forward(self, means3D, means2D, opacities, sh_indices, g_indices, shs=None, colors_precomp=None, scales=None,
                 scale_factors=None, rotations=None, cov3D_precomp=None, extrinsic_vector=None):
