@@ -205,32 +205,64 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
 // ---- K5: one (tile, Gaussian) pair per Gaussian x tile, reference rasterizer_impl.cu:70-111, walked in
 // (depth, id) order (binning.hip explains why). Thread k handles the k-th nearest Gaussian. Also stamps the
 // id-ordered instance slot offset into the splat record (word 9) for the backward.
+// Load-balanced expansion: a workgroup owns 256 consecutive Gaussians of the depth order, whose pairs form ONE
+// contiguous output range; its threads walk that range (coalesced 2-byte / 4-byte stores) and find the owning
+// Gaussian of each output by binary search over the 256 scan values in LDS. A thread-per-Gaussian loop (the
+// reference's shape) strands 63 lanes behind the one big splat and scatters its stores.
 __global__ void __launch_bounds__(256)
 duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
                            const uint32_t* __restrict__ sorted_offsets, const uint16_t* __restrict__ rects,
                            float4* __restrict__ splat, const uint32_t* __restrict__ inst_offset, uint16_t* __restrict__ keys,
                            uint32_t* __restrict__ values, int grid_x)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= P) return;
-    const uint32_t i = order[k];
-    if (tiles_touched[i] == 0) return;           // == reference's radii[idx] > 0 (culled ones sort last)
-    uint32_t off = (k == 0) ? 0u : sorted_offsets[k - 1];          // where this Gaussian's pairs go (depth order)
-    const uint32_t slot0 = (i == 0) ? 0u : inst_offset[i - 1];     // where its backward partial sums go (id order)
-    reinterpret_cast<float*>(splat + 3 * (size_t)i + 2)[1] = __uint_as_float(slot0);
-    const uint2 rc = *reinterpret_cast<const uint2*>(rects + 4 * (size_t)i);
-    const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            keys[off] = (uint16_t)(y * grid_x + x);
-            values[off] = i;
-            off++;
+    __shared__ uint32_t s_end[256];      // inclusive scan value of each of the block's Gaussians
+    __shared__ uint32_t s_id[256];
+    __shared__ uint2 s_rect[256];
+    const int t = threadIdx.x;
+    const int k0 = blockIdx.x * 256, k = k0 + t;
+    const uint32_t out_begin = (k0 == 0) ? 0u : sorted_offsets[k0 - 1];
+    uint32_t my_end = out_begin;
+    if (k < P) {
+        const uint32_t i = order[k];
+        my_end = sorted_offsets[k];
+        s_id[t] = i;
+        s_rect[t] = *reinterpret_cast<const uint2*>(rects + 4 * (size_t)i);   // the only gather by id (culled: unused)
+    }
+    s_end[t] = my_end;
+    __syncthreads();
+    const int nk = min(256, P - k0);
+    const uint32_t out_end = s_end[nk - 1];
+    for (uint32_t o = out_begin + t; o < out_end; o += 256) {
+        int lo = 0, hi = nk - 1;                  // first Gaussian whose inclusive end is > o
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_end[mid] > o) hi = mid; else lo = mid + 1;
         }
+        const uint32_t first = (lo == 0) ? out_begin : s_end[lo - 1];
+        const uint2 rc = s_rect[lo];
+        const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
+        const uint32_t local = o - first, w = (uint32_t)(x1 - x0);
+        const uint32_t ry = local / w, rx = local - ry * w;       // emission order: y outer, x inner (:98-108)
+        keys[o] = (uint16_t)((y0 + ry) * grid_x + (x0 + rx));
+        values[o] = s_id[lo];
+    }
+}
+
+// stamps the id-ordered exclusive instance offset (= first backward partial-sum slot) into the splat record
+__global__ void __launch_bounds__(256)
+stamp_slots_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ inst_offset,
+                   float4* __restrict__ splat)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P || tiles_touched[i] == 0) return;
+    const uint32_t slot0 = (i == 0) ? 0u : inst_offset[i - 1];
+    reinterpret_cast<float*>(splat + 3 * (size_t)i + 2)[1] = __uint_as_float(slot0);
 }
 
 void launch_duplicate_with_keys(int P, const GeomPtrs& g, const int32_t* /*radii*/, const BinPtrs& b, int grid_x, hipStream_t s)
 {
     if (P <= 0) return;
+    stamp_slots_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.tiles_touched, g.inst_offset, g.splat);
     duplicate_with_keys_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.depth_order, g.tiles_touched, g.sorted_offsets, g.rects,
                                                                g.splat, g.inst_offset, b.keys_unsorted, b.values_unsorted, grid_x);
 }
