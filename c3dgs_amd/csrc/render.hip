@@ -232,15 +232,39 @@ __device__ __forceinline__ int reduced_index_of_lane(int l)
            ((l >> 5) & 1);
 }
 
+// Steps 1 and 2 pair lanes that sit in different DPP banks (4-lane groups), so "which half do I keep" is
+// expressed by the instruction's bank_mask instead of v_cndmask selects: per output two v_add_f32_dpp that each
+// write half of the row's banks. Hand-placed because hipcc cannot emit bank-masked DPP adds from builtins (it
+// selects with v_cndmask and pads every DPP read with s_nop: 237 instructions for the network vs ~150 here).
+// The leading s_nop 1 covers the VALU-write -> DPP-read hazard for operands produced just before the block.
+#define C3DGS_TR4(CTRL, LO, HI, o, a, b, base, half)                                                                      \
+    asm volatile("s_nop 1\n\t"                                                                                            \
+                 "v_add_f32_dpp %0, %4, %4 " CTRL " row_mask:0xf bank_mask:" LO "\n\t"                                    \
+                 "v_add_f32_dpp %1, %5, %5 " CTRL " row_mask:0xf bank_mask:" LO "\n\t"                                    \
+                 "v_add_f32_dpp %2, %6, %6 " CTRL " row_mask:0xf bank_mask:" LO "\n\t"                                    \
+                 "v_add_f32_dpp %3, %7, %7 " CTRL " row_mask:0xf bank_mask:" LO "\n\t"                                    \
+                 "v_add_f32_dpp %0, %8, %8 " CTRL " row_mask:0xf bank_mask:" HI "\n\t"                                    \
+                 "v_add_f32_dpp %1, %9, %9 " CTRL " row_mask:0xf bank_mask:" HI "\n\t"                                    \
+                 "v_add_f32_dpp %2, %10, %10 " CTRL " row_mask:0xf bank_mask:" HI "\n\t"                                  \
+                 "v_add_f32_dpp %3, %11, %11 " CTRL " row_mask:0xf bank_mask:" HI                                         \
+                 : "=&v"(o[base]), "=&v"(o[base + 1]), "=&v"(o[base + 2]), "=&v"(o[base + 3])                             \
+                 : "v"(a[base]), "v"(a[base + 1]), "v"(a[base + 2]), "v"(a[base + 3]), "v"(b[base + half]),               \
+                   "v"(b[base + half + 1]), "v"(b[base + half + 2]), "v"(b[base + half + 3]))
+
 __device__ __forceinline__ float transpose_reduce_64(float* v, int lane)
 {
-    transpose_reduce_step<64, 0x128>(v, (lane & 8) != 0);  // row_ror:8
-    transpose_reduce_step<32, 0x141>(v, (lane & 4) != 0);  // row_half_mirror
-    transpose_reduce_step<16, 0xB1>(v, (lane & 1) != 0);   // quad_perm [1,0,3,2]
-    transpose_reduce_step<8, 0x4E>(v, (lane & 2) != 0);    // quad_perm [2,3,0,1]
-    // rows: v[0..3] indexed (b1,b0); odd rows keep b1 = 1
-    auto s0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
-    auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+    float w[32], u[16];
+    // 64 -> 32: row_ror:8 (lane i <-> i^8); lanes 0-7 = banks 0,1 keep v[k], lanes 8-15 = banks 2,3 keep v[k+32]
+#pragma unroll
+    for (int q = 0; q < 32; q += 4) C3DGS_TR4("row_ror:8", "0x3", "0xc", w, v, v, q, 32);
+    // 32 -> 16: row_half_mirror (i <-> i^7); lanes with bit 2 clear = banks 0,2 keep w[k], banks 1,3 keep w[k+16]
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, w, w, q, 16);
+    transpose_reduce_step<16, 0xB1>(u, (lane & 1) != 0);   // quad_perm [1,0,3,2]: partners share a bank -> selects
+    transpose_reduce_step<8, 0x4E>(u, (lane & 2) != 0);    // quad_perm [2,3,0,1]
+    // rows: u[0..3] indexed (b1,b0); odd rows keep b1 = 1
+    auto s0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[0]), __float_as_uint(u[2]), false, false);
+    auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[1]), __float_as_uint(u[3]), false, false);
     const float w0 = __uint_as_float(s0[0]) + __uint_as_float(s0[1]);
     const float w1 = __uint_as_float(s1[0]) + __uint_as_float(s1[1]);
     auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w0), __float_as_uint(w1), false, false);
