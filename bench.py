@@ -160,6 +160,13 @@ def main():
                                                   "render_forward", "zero_partials", "render_backward",
                                                   "backward_preprocess", "mark_visible")]
     dom = max(raster_stages, key=lambda k: stage_ms[k])
+    traffic = None
+    try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/pmc_traffic.sh)
+        if P == 3_000_000 and (W, H) == (1920, 1080):
+            with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
     dom_bytes = alg_bytes(dom, P, V, R, T, N, 16, bit, indexed=True)
     dom_gbs = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
     view_bytes = sum(alg_bytes(k, P, V, R, T, N, 16, bit, True) for k in raster_stages)
@@ -183,7 +190,7 @@ def main():
                    "sh_codebook": int(t["shs"].shape[0]), "gaussian_codebook": int(t["scales"].shape[0]),
                    "parallelism": f"replicas x{world}"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": dom_gbs / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": dom_bytes,
+                     "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": dom_bytes,
                      "avg_launch_ms": stage_ms[dom]},
         "stages_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])},
         "view_alg_bytes": view_bytes,

@@ -1,0 +1,45 @@
+"""Summarise FETCH_SIZE / WRITE_SIZE PMC passes into HBM bytes per launch for each c3dgs kernel.
+
+Units and corrections (MI355X_MICROARCH.md, section HBM): both counters are in KiB; on gfx950 FETCH_SIZE reports exactly
+1/2 of the bytes of a wide coalesced streaming read (128-B requests tallied at 64 B), so it is DOUBLED here; WRITE_SIZE
+reads exactly for streaming stores and float atomics. Gather-heavy kernels are uncalibrated for the x2 (stated in the
+output as `fetch_x2_applied`)."""
+import collections
+import csv
+import json
+import re
+import sys
+
+STAGE = [("mark_visible", "mark_visible"), ("backward_preprocess", "backward_preprocess"), ("preprocess_kernel", "preprocess"),
+         ("duplicate_with_keys", "duplicate_with_keys"), ("stamp_slots", "duplicate_with_keys"),
+         ("identify_ranges", "identify_ranges"), ("render_forward", "render_forward"), ("render_backward", "render_backward"),
+         ("wd_mfma48", "weighted_distance"), ("weighted_distance_kernel", "weighted_distance")]
+
+
+def load(path, counter):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"]
+        for key, stage in STAGE:
+            if key in name:
+                per[stage].append(float(r["Counter_Value"]))
+                break
+    return per
+
+
+fetch = load(sys.argv[1], "FETCH_SIZE")
+write = load(sys.argv[2], "WRITE_SIZE")
+out = {}
+for st in sorted(set(fetch) | set(write)):
+    f = fetch.get(st, [0.0])
+    w = write.get(st, [0.0])
+    # warm launches only: drop the first one
+    f = f[1:] if len(f) > 1 else f
+    w = w[1:] if len(w) > 1 else w
+    fb = 2.0 * 1024.0 * sum(f) / len(f)
+    wb = 1024.0 * sum(w) / len(w)
+    out[st] = {"hbm_bytes_per_launch": fb + wb, "fetch_bytes": fb, "write_bytes": wb, "fetch_x2_applied": True,
+               "launches_averaged": len(f)}
+print(json.dumps(out, indent=1))
