@@ -124,6 +124,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(6):          # set-up, not warm-up: lets torch's caching allocator reach its steady-state block set
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -266,30 +268,38 @@ def bench_vq(c3dgs_amd, _lib, dev, rank, world, steps):
 
 
 def cpu_baseline(ix_cpu, intr, ev, W, H, focal):
-    """The oracle (`kind: port`) on the host cores: one fwd+bwd view of a Gaussian SUBSAMPLE of the same scene at the
-    same resolution, scaled linearly to the full Gaussian count (the per-pixel blend cost grows with density, so the
-    scaled figure slightly flatters the CPU)."""
+    """The oracle (`kind: port`, oracle/c3dgs_oracle.c, OpenMP) on this box's host cores: one fwd+bwd view of the SAME
+    workload. A 10 % Gaussian subsample is timed first; if that predicts more than ~45 s for the full view the scaled
+    subsample figure is reported instead (the sample field says which)."""
     import numpy as np
     from oracle import oracle as orc
     from tests import synth
     cam = orc.camera(intr.numpy(), ev.numpy())
     P = ix_cpu["means3D"].shape[0]
-    sub = max(1, P // 10)
-    sel = slice(0, sub)
     dL = synth.grad_image(W, H).numpy()
-    t0 = time.perf_counter()
-    st = orc.rasterize_forward(bg=np.zeros(3, np.float32), means3D=ix_cpu["means3D"][sel].numpy(),
-                               opacities=ix_cpu["opacities"][sel].numpy(), shs=ix_cpu["shs"].numpy(),
-                               scales=ix_cpu["scales"].numpy(), rotations=ix_cpu["rotations"].numpy(),
-                               scale_factors=ix_cpu["scale_factors"][sel].numpy(),
-                               sh_indices=ix_cpu["sh_indices"][sel].numpy(), g_indices=ix_cpu["g_indices"][sel].numpy(),
-                               degree=3, clamp_color=True, **cam)
-    orc.rasterize_backward(st, dL)
-    dt = time.perf_counter() - t0
+
+    def run(n):
+        sel = slice(0, n)
+        t0 = time.perf_counter()
+        st = orc.rasterize_forward(bg=np.zeros(3, np.float32), means3D=ix_cpu["means3D"][sel].numpy(),
+                                   opacities=ix_cpu["opacities"][sel].numpy(), shs=ix_cpu["shs"].numpy(),
+                                   scales=ix_cpu["scales"].numpy(), rotations=ix_cpu["rotations"].numpy(),
+                                   scale_factors=ix_cpu["scale_factors"][sel].numpy(),
+                                   sh_indices=ix_cpu["sh_indices"][sel].numpy(), g_indices=ix_cpu["g_indices"][sel].numpy(),
+                                   degree=3, clamp_color=True, **cam)
+        orc.rasterize_backward(st, dL)
+        return time.perf_counter() - t0, st.num_rendered
+
+    sub = max(1, P // 10)
+    dt_sub, r_sub = run(sub)
+    if dt_sub * (P / sub) <= 45.0:
+        dt, r = run(P)
+        return {"value": 1.0 / dt, "unit": "views/s", "cores": orc.num_threads(), "kind": "port",
+                "sample": f"1 full view fwd+bwd, {P} Gaussians at {W}x{H} ({dt:.2f} s, R={r}); oracle/c3dgs_oracle.c, OpenMP"}
     scale = P / sub
-    return {"value": 1.0 / (dt * scale), "unit": "views/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"1 view fwd+bwd of the first {sub} of {P} Gaussians at {W}x{H} ({dt:.2f} s, R={st.num_rendered}), "
-                      f"time scaled x{scale:.0f}; oracle/c3dgs_oracle.c with OpenMP"}
+    return {"value": 1.0 / (dt_sub * scale), "unit": "views/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"1 view fwd+bwd of the first {sub} of {P} Gaussians at {W}x{H} ({dt_sub:.2f} s, R={r_sub}), "
+                      f"time scaled x{scale:.0f}; oracle/c3dgs_oracle.c, OpenMP"}
 
 
 if __name__ == "__main__":

@@ -117,7 +117,7 @@ weighted_distance_generic_kernel(int64_t N, int C, int K, const float* __restric
 }
 
 
-// ---------------------------------------------------------------- MFMA nearest-codeword search (K = 48)
+// ---------------------------------------------------------------- MFMA nearest-codeword search (K = 48, 12, 6)
 //
 // s[c][n] = ||c||^2 - 2 x_n.c  (argmin_c s == argmin_c ||x_n - c||^2) on the fp32 matrix cores:
 // v_mfma_f32_32x32x2_f32 with A = 32 codewords x 2 dims (from an LDS tile stored k-major, conflict-free),
@@ -132,7 +132,6 @@ weighted_distance_generic_kernel(int64_t N, int C, int K, const float* __restric
 // wd_fixup_kernel with the exact chain over all codewords (lowest index wins ties).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int MF_K = 48;
 constexpr int MF_CT = 128;          // codewords per LDS tile
 constexpr int MF_PTS = 64;          // points per wave (two 32-point B operands)
 
@@ -144,10 +143,12 @@ __device__ __forceinline__ void top2_update(float v, int row, float& best, float
     second = fminf(second, hi);
 }
 
+template <int MF_K>
 __global__ void __launch_bounds__(256)
-wd_mfma48_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather,
-                 const float* __restrict__ codebook, float* __restrict__ out_dist, int64_t* __restrict__ out_idx)
+wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather,
+               const float* __restrict__ codebook, float* __restrict__ out_dist, int64_t* __restrict__ out_idx)
 {
+    static_assert(MF_K % 2 == 0, "two dims per v_mfma_f32_32x32x2_f32 step");
     __shared__ float s_cb[2][MF_K][MF_CT];   // k-major tile: lane i reads s_cb[k][i] (consecutive banks)
     __shared__ float s_norm[2][MF_CT];
 
@@ -180,16 +181,27 @@ wd_mfma48_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_
 
     const int ntiles = (C + MF_CT - 1) / MF_CT;
     auto stage = [&](int tile, int buf) {
-        // one codeword per thread pair: thread t stages codeword (t & 127), dims [24*(t>>7), 24*(t>>7)+24)
-        const int c = tid & (MF_CT - 1), half = tid >> 7;
-        const int cg = tile * MF_CT + c;
-        const float4* src = reinterpret_cast<const float4*>(codebook + (size_t)(cg < C ? cg : 0) * MF_K + 24 * half);
+        if constexpr (MF_K % 8 == 0) {
+            // one codeword per thread pair: thread t stages codeword (t & 127), dims [K/2*(t>>7), K/2*(t>>7)+K/2)
+            const int c = tid & (MF_CT - 1), half = tid >> 7;
+            const int cg = tile * MF_CT + c;
+            const float4* src = reinterpret_cast<const float4*>(codebook + (size_t)(cg < C ? cg : 0) * MF_K + (MF_K / 2) * half);
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            float4 v = src[q];
-            if (cg >= C) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int k = 24 * half + 4 * q;
-            s_cb[buf][k][c] = v.x; s_cb[buf][k + 1][c] = v.y; s_cb[buf][k + 2][c] = v.z; s_cb[buf][k + 3][c] = v.w;
+            for (int q = 0; q < MF_K / 8; q++) {
+                float4 v = src[q];
+                if (cg >= C) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int k = (MF_K / 2) * half + 4 * q;
+                s_cb[buf][k][c] = v.x; s_cb[buf][k + 1][c] = v.y; s_cb[buf][k + 2][c] = v.z; s_cb[buf][k + 3][c] = v.w;
+            }
+        } else if (tid < MF_CT) {                  // small K: one codeword per thread, 8-byte loads
+            const int cg = tile * MF_CT + tid;
+            const float2* src = reinterpret_cast<const float2*>(codebook + (size_t)(cg < C ? cg : 0) * MF_K);
+#pragma unroll
+            for (int q = 0; q < MF_K / 2; q++) {
+                float2 v = src[q];
+                if (cg >= C) v = make_float2(0.f, 0.f);
+                s_cb[buf][2 * q][tid] = v.x; s_cb[buf][2 * q + 1][tid] = v.y;
+            }
         }
     };
     stage(0, 0);
@@ -307,11 +319,16 @@ int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const 
     const bool al16 = (((uintptr_t)coefs | (uintptr_t)codebook) & 15) == 0;
     const bool al8 = (((uintptr_t)coefs | (uintptr_t)codebook) & 7) == 0;
     static const bool force_exact = getenv("C3DGS_VQ_EXACT_VALU") != nullptr;   // A/B switch for tests and profiling
+    const unsigned g1 = (unsigned)((N + 4 * MF_PTS - 1) / (4 * MF_PTS)), g2 = (unsigned)((N + 255) / 256);
     if (K == 48 && al16 && C >= 32 && !force_exact) {
-        const unsigned g1 = (unsigned)((N + 4 * MF_PTS - 1) / (4 * MF_PTS));
-        wd_mfma48_kernel<<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
-        const unsigned g2 = (unsigned)((N + 255) / 256);
+        wd_mfma_kernel<48><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
         wd_fixup_kernel<48><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
+    } else if (K == 12 && al8 && C >= 32 && !force_exact) {
+        wd_mfma_kernel<12><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
+        wd_fixup_kernel<12><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
+    } else if (K == 6 && al8 && C >= 32 && !force_exact) {
+        wd_mfma_kernel<6><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
+        wd_fixup_kernel<6><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
     } else if (K == 48 && al16) weighted_distance_kernel<48, 128><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
     else if (K == 12 && al16) weighted_distance_kernel<12, 512><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
     else if (K == 6 && al8) weighted_distance_kernel<6, 1024><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
@@ -342,6 +359,38 @@ vq_accumulate_kernel(int64_t B, int D, const float* __restrict__ x, const float*
     }
 }
 
+// Small tables (K*(D+1) <= 16 K floats, e.g. the covariance codebook: 2048 x 7 = 56 KB) are accumulated in a
+// per-workgroup LDS copy first: a million points hammering 2048 rows with global float atomics serialise at the
+// memory side (MI355X_MICROARCH.md: "every workgroup into ONE row: 14x slower"), LDS atomics do not leave the CU.
+constexpr int VQ_LDS_FLOATS = 16384;
+
+__global__ void __launch_bounds__(256)
+vq_accumulate_lds_kernel(int64_t B, int K, int D, const float* __restrict__ x, const float* __restrict__ w,
+                         const int64_t* __restrict__ gather, const int64_t* __restrict__ idx, float* __restrict__ S)
+{
+    __shared__ float s_S[VQ_LDS_FLOATS];
+    const int D1 = D + 1, table = K * D1;
+    for (int q = threadIdx.x; q < table; q += 256) s_S[q] = 0.f;
+    __syncthreads();
+    const int64_t total = B * D1;
+    // contiguous slab of elements per workgroup (keeps a point's D+1 adds together)
+    const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+    const int64_t e0 = (int64_t)blockIdx.x * per, e1 = e0 + per < total ? e0 + per : total;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int64_t n = e / D1;
+        const int c = (int)(e - n * D1);
+        const int64_t row = gather ? gather[n] : n;
+        const float wn = w[row];
+        const float v = (c < D) ? x[row * D + c] * wn : wn;
+        atomicAdd(&s_S[(int)idx[n] * D1 + c], v);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < table; q += 256) {
+        const float v = s_S[q];
+        if (v != 0.f) atomicAdd(S + q, v);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 vq_dist_sum_kernel(int64_t B, const float* __restrict__ dist, double* __restrict__ out)
 {
@@ -363,8 +412,13 @@ void launch_vq_accumulate(int64_t B, int K, int D, const float* x, const float* 
     (void)K;
     if (B <= 0) return;
     const int64_t total = B * (D + 1);
-    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 16);
-    vq_accumulate_kernel<<<grid, 256, 0, s>>>(B, D, x, w, gather, idx, S);
+    if ((int64_t)K * (D + 1) <= VQ_LDS_FLOATS && total >= (int64_t)1 << 16) {
+        const unsigned grid = (unsigned)std::min<int64_t>((total + 4095) / 4096, 512);
+        vq_accumulate_lds_kernel<<<grid, 256, 0, s>>>(B, K, D, x, w, gather, idx, S);
+    } else {
+        const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 16);
+        vq_accumulate_kernel<<<grid, 256, 0, s>>>(B, D, x, w, gather, idx, S);
+    }
     if (dist && dist_sum) {
         const unsigned g2 = (unsigned)std::min<int64_t>((B + 255) / 256, 1024);
         vq_dist_sum_kernel<<<g2, 256, 0, s>>>(B, dist, dist_sum);

@@ -13,7 +13,7 @@ import sys
 STAGE = [("mark_visible", "mark_visible"), ("backward_preprocess", "backward_preprocess"), ("preprocess_kernel", "preprocess"),
          ("duplicate_with_keys", "duplicate_with_keys"), ("stamp_slots", "duplicate_with_keys"),
          ("identify_ranges", "identify_ranges"), ("render_forward", "render_forward"), ("render_backward", "render_backward"),
-         ("wd_mfma48", "weighted_distance"), ("weighted_distance_kernel", "weighted_distance")]
+         ("wd_mfma", "weighted_distance"), ("weighted_distance_kernel", "weighted_distance")]
 
 
 def load(path, counter):
