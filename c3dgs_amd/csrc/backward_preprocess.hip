@@ -17,6 +17,12 @@
 #ifndef C3DGS_ABLATE_GS
 #define C3DGS_ABLATE_GS 0
 #endif
+#ifndef C3DGS_ABLATE_STAGE
+#define C3DGS_ABLATE_STAGE 0
+#endif
+#ifndef C3DGS_ABLATE_SHMATH
+#define C3DGS_ABLATE_SHMATH 0
+#endif
 
 namespace c3dgs {
 
@@ -147,7 +153,7 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
         if (i >= a.P) start_ = end_;
         const uint32_t w_begin = __builtin_amdgcn_readfirstlane(start_);
         const uint32_t w_end = __builtin_amdgcn_readlane(end_, 63);
-        for (uint32_t c0 = w_begin; c0 < w_end; c0 += CH) {
+        for (uint32_t c0 = w_begin; c0 < (C3DGS_ABLATE_STAGE ? w_begin : w_end); c0 += CH) {
             const uint32_t n = min((uint32_t)CH, w_end - c0);
 #pragma unroll
             for (int k = 0; k < CH / 64; k++) {
@@ -286,7 +292,7 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
     dmean[2] += (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
 
     // ---- SH (backward.cu:20-139 / backward_indexed.cu:20-201)
-    if (a.sh) {
+    if (a.sh && !C3DGS_ABLATE_SHMATH) {
         const size_t row = INDEXED ? (size_t)a.sh_indices[i] : si;
         const float* shp = a.sh + row * (size_t)a.M * 3;
         constexpr int NC = (DEG + 1) * (DEG + 1) * 3;
