@@ -71,6 +71,10 @@ PROTOTYPES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c3dgs_vq_apply": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_int32, C.c_void_p]),
+    "c3dgs_l1_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "c3dgs_l1_ssim_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "c3dgs_get_geom_layout": (C.c_int, [C.c_int32, C.POINTER(GeomLayout)]),
     "c3dgs_get_binning_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(BinningLayout)]),
     "c3dgs_get_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(ImageLayout)]),

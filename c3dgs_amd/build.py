@@ -27,6 +27,7 @@ SOURCES = {
     # SLP packing into v_pk_*_f32 costs register shuffles in the blend loops and keeps DPP adds from fusing
     "render.hip": os.environ.get("C3DGS_RENDER_FLAGS", "-fno-slp-vectorize").split(),
     "vq.hip": [],
+    "loss.hip": [],
 }
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gsmath.hpp"),
            os.path.join(HERE, "..", "include", "c3dgs_hip.h")]

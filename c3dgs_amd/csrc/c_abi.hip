@@ -14,10 +14,11 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 // Disabled by default: zero cost. When enabled, every stage launch is bracketed by two events; nothing
 // synchronises until c3dgs_profile_read().
 enum Stage { ST_MARK_VISIBLE, ST_PREPROCESS, ST_DEPTH_SORT, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_ZERO_PARTIALS,
-             ST_RENDER_BWD, ST_BWD_PREPROCESS, ST_WDIST, ST_VQ_ACC, ST_VQ_APPLY, ST_COUNT };
+             ST_RENDER_BWD, ST_BWD_PREPROCESS, ST_WDIST, ST_VQ_ACC, ST_VQ_APPLY, ST_LOSS_FWD, ST_LOSS_BWD, ST_COUNT };
 static const char* kStageNames[ST_COUNT] = { "mark_visible", "preprocess", "depth_sort", "scan", "duplicate_with_keys", "sort",
                                              "identify_ranges", "render_forward", "zero_partials", "render_backward",
-                                             "backward_preprocess", "weighted_distance", "vq_accumulate", "vq_apply" };
+                                             "backward_preprocess", "weighted_distance", "vq_accumulate", "vq_apply", "l1_ssim_forward",
+                                             "l1_ssim_backward" };
 struct ProfRec { int stage; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -344,6 +345,36 @@ int c3dgs_vq_apply(int32_t K, int32_t D, const float* S, float* codebook, float*
     if (K <= 0 || D <= 0 || !S || !codebook || !entry_importance) return fail(C3DGS_E_INVALID, "bad arguments");
     { StageTimer t_(ST_VQ_APPLY, (hipStream_t)stream); launch_vq_apply(K, D, S, codebook, entry_importance, decay, alpha, eps, scale_normalize, (hipStream_t)stream); }
     C3DGS_STAGE("vq_apply", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, float* dmaps, double* sums,
+                          void* stream)
+{
+    if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !sums) return fail(C3DGS_E_INVALID, "l1_ssim_forward: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    C3DGS_HIP_TRY(hipMemsetAsync(sums, 0, 128 * sizeof(double), s));
+    const size_t n = (size_t)C * H * W;
+    {
+        StageTimer t_(ST_LOSS_FWD, s);
+        launch_l1_ssim_forward(C, H, W, img, gt, dmaps, dmaps ? dmaps + n : nullptr, dmaps ? dmaps + 2 * n : nullptr, sums, s);
+    }
+    C3DGS_STAGE("l1_ssim_forward", 0, s);
+    return C3DGS_OK;
+}
+
+int c3dgs_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, const float* dmaps,
+                           const float* grad_loss, float l1_coeff, float ssim_coeff, float* dL_dimg, void* stream)
+{
+    if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !dmaps || !grad_loss || !dL_dimg)
+        return fail(C3DGS_E_INVALID, "l1_ssim_backward: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)C * H * W;
+    {
+        StageTimer t_(ST_LOSS_BWD, s);
+        launch_l1_ssim_backward(C, H, W, img, gt, dmaps, dmaps + n, dmaps + 2 * n, grad_loss, l1_coeff, ssim_coeff, dL_dimg, s);
+    }
+    C3DGS_STAGE("l1_ssim_backward", 0, s);
     return C3DGS_OK;
 }
 

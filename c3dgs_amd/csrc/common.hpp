@@ -165,4 +165,11 @@ void launch_vq_accumulate(int64_t B, int K, int D, const float* x, const float* 
 void launch_vq_apply(int K, int D, const float* S, float* codebook, float* entry_importance, float decay, float alpha,
                      float eps, int scale_normalize, hipStream_t s);
 
+// loss.hip
+void launch_l1_ssim_forward(int C, int H, int W, const float* img, const float* gt, float* Dmu, float* Ds1, float* Ds12,
+                            double* sums, hipStream_t s);
+void launch_l1_ssim_backward(int C, int H, int W, const float* img, const float* gt, const float* Dmu, const float* Ds1,
+                             const float* Ds12, const float* grad_loss, float l1_coeff, float ssim_coeff, float* dL_dimg,
+                             hipStream_t s);
+
 } // namespace c3dgs

@@ -142,6 +142,19 @@ int c3dgs_vq_accumulate(int64_t B, int32_t K, int32_t D, const float* x, const f
 int c3dgs_vq_apply(int32_t K, int32_t D, const float* S, float* codebook, float* entry_importance,
                    float decay, float alpha, float eps, int32_t scale_normalize, void* stream);
 
+/* ---- L1 + SSIM loss (reference utils/loss_utils.py:17-63, used at finetune.py:48) ----
+ * forward: sums[0..63] add up to sum |img - gt|, sums[64..127] to sum ssim_map (float64, device, zeroed by the callee;
+ * 64 partial accumulators each so that the per-workgroup atomics do not serialise on one address); 11x11 Gaussian
+ * window sigma 1.5, zero padding, per channel. dmaps (3*C*H*W floats, may be NULL when no backward is needed)
+ * receives the three partial-derivative maps the backward consumes.
+ * backward: for a scalar  L = l1_coeff * mean|img-gt| + ssim_coeff * mean(ssim_map) + const  (QAT: 1-lambda, -lambda)
+ * writes dL_dimg = grad_loss[0] * dL/dimg  ([C,H,W], fully written). */
+int c3dgs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, float* dmaps,
+                          double* sums /*[128]*/, void* stream);
+int c3dgs_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, const float* dmaps,
+                           const float* grad_loss /*device [1]*/, float l1_coeff, float ssim_coeff, float* dL_dimg,
+                           void* stream);
+
 /* ---- introspection (tests and profiling only) ---- */
 typedef struct c3dgs_geom_layout {   /* byte offsets into the geometry buffer for P Gaussians */
     size_t total_bytes;

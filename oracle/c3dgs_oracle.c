@@ -840,3 +840,84 @@ void orc_test_cov3d(int n, const float* scales, float mod, const float* rots, fl
 {
     for (int i = 0; i < n; i++) cov3d_from_scale_rot(scales + 3 * i, mod, rots + 4 * i, cov + 6 * i);
 }
+
+/* ---------------------------------------------------------------- N3: L1 + SSIM loss (utils/loss_utils.py:17-63)
+ * loss = (1-lambda)*mean|x-y| + lambda*(1 - mean(ssim_map)), the QAT loss of finetune.py:48.
+ * ssim: 11x11 Gaussian window (sigma 1.5, normalised in fp32 like `gaussian`/`create_window`, :23-31), zero padding 5,
+ * per channel; direct 121-tap sums in float64. dL_dimg (may be NULL) is the analytic gradient w.r.t. img. */
+void orc_l1_ssim(int C, int H, int W, const float* img, const float* gt, double lambda, double* out /*[3]: loss, l1, ssim*/,
+                 float* dL_dimg)
+{
+    float g[11], gs = 0.f;
+    for (int i = 0; i < 11; i++) { g[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); gs += g[i]; }
+    for (int i = 0; i < 11; i++) g[i] = g[i] / gs;
+    float w2[11][11];
+    for (int i = 0; i < 11; i++) for (int j = 0; j < 11; j++) w2[i][j] = g[i] * g[j];
+    const double C1 = 0.01 * 0.01, C2 = 0.03 * 0.03;
+    const size_t HW = (size_t)H * W, N = (size_t)C * HW;
+    double* Dmu = (double*)calloc(N + 1, sizeof(double));
+    double* Ds1 = (double*)calloc(N + 1, sizeof(double));
+    double* Ds12 = (double*)calloc(N + 1, sizeof(double));
+    double ssim_sum = 0.0, l1_sum = 0.0;
+#pragma omp parallel for reduction(+ : ssim_sum, l1_sum) schedule(static)
+    for (int cy = 0; cy < C * H; cy++) {
+        const int c = cy / H, y = cy % H;
+        const float* X = img + (size_t)c * HW;
+        const float* Y = gt + (size_t)c * HW;
+        for (int x = 0; x < W; x++) {
+            double mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+            for (int i = 0; i < 11; i++) {
+                const int yy = y + i - 5;
+                if (yy < 0 || yy >= H) continue;
+                for (int j = 0; j < 11; j++) {
+                    const int xx = x + j - 5;
+                    if (xx < 0 || xx >= W) continue;
+                    const double wv = w2[i][j], a = X[(size_t)yy * W + xx], b = Y[(size_t)yy * W + xx];
+                    mu1 += wv * a; mu2 += wv * b; e11 += wv * a * a; e22 += wv * b * b; e12 += wv * a * b;
+                }
+            }
+            const double s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+            const double A = 2 * mu1 * mu2 + C1, B = 2 * s12 + C2, Cc = mu1 * mu1 + mu2 * mu2 + C1, Dd = s1 + s2 + C2;
+            const double m = (A * B) / (Cc * Dd);
+            ssim_sum += m;
+            const size_t p = (size_t)c * HW + (size_t)y * W + x;
+            l1_sum += fabs((double)X[(size_t)y * W + x] - (double)Y[(size_t)y * W + x]);
+            /* partials of m w.r.t. (mu1, E[x^2], E[xy]) with mu2, E[y^2] fixed */
+            const double dm_ds1 = -A * B / (Cc * Dd * Dd);
+            const double dm_ds12 = 2 * A / (Cc * Dd);
+            const double dm_dmu1_s = (2 * mu2 * B) / (Cc * Dd) - (A * B * 2 * mu1) / (Cc * Cc * Dd);
+            Dmu[p] = dm_dmu1_s - 2 * mu1 * dm_ds1 - mu2 * dm_ds12;
+            Ds1[p] = dm_ds1;
+            Ds12[p] = dm_ds12;
+        }
+    }
+    const double l1 = l1_sum / (double)N, ss = ssim_sum / (double)N;
+    out[0] = (1.0 - lambda) * l1 + lambda * (1.0 - ss);
+    out[1] = l1;
+    out[2] = ss;
+    if (dL_dimg) {
+#pragma omp parallel for schedule(static)
+        for (int cy = 0; cy < C * H; cy++) {
+            const int c = cy / H, y = cy % H;
+            for (int x = 0; x < W; x++) {
+                const size_t p = (size_t)c * HW + (size_t)y * W + x;
+                double a = 0, b = 0, d = 0;
+                for (int i = 0; i < 11; i++) {
+                    const int yy = y + i - 5;
+                    if (yy < 0 || yy >= H) continue;
+                    for (int j = 0; j < 11; j++) {
+                        const int xx = x + j - 5;
+                        if (xx < 0 || xx >= W) continue;
+                        const size_t q = (size_t)c * HW + (size_t)yy * W + xx;
+                        const double wv = w2[i][j];
+                        a += wv * Dmu[q]; b += wv * Ds1[q]; d += wv * Ds12[q];
+                    }
+                }
+                const double xv = img[p], yv = gt[p];
+                const double sgn = xv > yv ? 1.0 : (xv < yv ? -1.0 : 0.0);
+                dL_dimg[p] = (float)((1.0 - lambda) * sgn / (double)N - lambda * (a + 2 * xv * b + yv * d) / (double)N);
+            }
+        }
+    }
+    free(Dmu); free(Ds1); free(Ds12);
+}

@@ -108,6 +108,10 @@ void orc_vq_trace_normalize(int K, int D, float* codebook);
 
 int orc_num_threads(void);
 
+/* N3: L1 + SSIM loss of finetune.py:48 / utils/loss_utils.py:17-63 and its gradient w.r.t. img */
+void orc_l1_ssim(int C, int H, int W, const float* img, const float* gt, double lambda, double* out /*[3]*/,
+                 float* dL_dimg /*[C,H,W] or NULL*/);
+
 /* test hooks: expose the per-Gaussian SH->RGB and cov3D helpers for golden-vector pinning */
 void orc_test_color_from_sh(int n, int deg, int M, const float* pos, const float* campos, const float* sh,
                             int clamp_color, uint8_t* clamped, float* rgb);

@@ -81,6 +81,8 @@ def lib():
         _lib.orc_num_threads.restype = C.c_int
         _lib.orc_test_color_from_sh.restype = None
         _lib.orc_test_color_from_sh.argtypes = [C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, _u8p, _f32p]
+        _lib.orc_l1_ssim.restype = None
+        _lib.orc_l1_ssim.argtypes = [C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_double, C.POINTER(C.c_double), _f32p]
         _lib.orc_test_cov3d.restype = None
         _lib.orc_test_cov3d.argtypes = [C.c_int, _f32p, C.c_float, _f32p, _f32p]
     return _lib
@@ -341,3 +343,14 @@ def cov3d(scales, mod, rotations):
     out = np.zeros((s.shape[0], 6), np.float32)
     lib().orc_test_cov3d(s.shape[0], _p(s, _f32p), float(mod), _p(q, _f32p), _p(out, _f32p))
     return out
+
+
+# ----------------------------------------------------------------------------- N3: loss
+def l1_ssim(img, gt, lambda_dssim=0.2, want_grad=True):
+    """(loss, l1, ssim, dL_dimg) of loss = (1-l)*L1 + l*(1-SSIM) (finetune.py:48, utils/loss_utils.py:17-63)."""
+    img, gt = _f32(img), _f32(gt)
+    Cc, H, W = img.shape
+    out = (C.c_double * 3)()
+    g = np.zeros_like(img) if want_grad else None
+    lib().orc_l1_ssim(Cc, H, W, _p(img, _f32p), _p(gt, _f32p), float(lambda_dssim), out, _p(g, _f32p))
+    return float(out[0]), float(out[1]), float(out[2]), g

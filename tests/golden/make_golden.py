@@ -9,6 +9,7 @@ What it pins; the fixtures hold data only (inputs + exp
                  argmin) and its RNG draws (rand_like of uniform_init, randint batches) captured as data
   sh.npz         utils/sh_utils.py:eval_sh                       -> K2's SH->RGB (before +0.5 / clamp)
   cov3d.npz      utils/general_utils.py:build_covariance_from_scaling_rotation -> K2's cov3D
+  loss.npz       utils/loss_utils.py: (1-l)*l1_loss + l*(1-ssim) and its autograd gradient (finetune.py:48)
   camgrad.npz    the closed-form grad_params block of _RasterizeGaussiansIndexedCamera.backward
                  (diff_gaussian_rasterization_no_camera/__init__.py:674-844), executed on CPU tensors
 """
@@ -139,6 +140,26 @@ def gen_camgrad():
     print("camgrad.npz")
 
 
+def gen_loss():
+    """finetune.py:48 loss and its autograd gradient, utils/loss_utils.py (pure torch, importable)."""
+    from utils.loss_utils import l1_loss, ssim
+    out = {}
+    for tag, (C_, H, W, seed) in {"a": (3, 37, 53, 0), "b": (3, 16, 16, 1), "c": (1, 9, 40, 2)}.items():
+        g = torch.Generator().manual_seed(seed)
+        gt = torch.rand(C_, H, W, generator=g)
+        img = (gt + 0.15 * torch.randn(C_, H, W, generator=g)).clamp(0, 1).requires_grad_()
+        lam = 0.2
+        s_ = ssim(img, gt)
+        l_ = l1_loss(img, gt)
+        loss = (1 - lam) * l_ + lam * (1 - s_)
+        loss.backward()
+        out.update({f"img_{tag}": img.detach().numpy(), f"gt_{tag}": gt.numpy(), f"loss_{tag}": np.array(float(loss.detach())),
+                    f"ssim_{tag}": np.array(float(s_.detach())), f"l1_{tag}": np.array(float(l_.detach())),
+                    f"grad_{tag}": img.grad.numpy()})
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+    print("loss.npz")
+
+
 if __name__ == "__main__":
     vq = shim_and_import_vq()
     gen_vq(vq, "vq_color.npz", N=3000, D=12, K=64, steps=12, chunk=1024, scale_normalize=False, seed=0)
@@ -146,3 +167,4 @@ if __name__ == "__main__":
     gen_sh()
     gen_cov3d()
     gen_camgrad()
+    gen_loss()

@@ -44,3 +44,14 @@ def test_cov3d_vs_reference(orc, mod):
     cov = orc.cov3d(d["scales"], mod, d["rotations"])
     ref = d[f"cov_mod{mod}"]
     np.testing.assert_allclose(cov, ref, rtol=2e-5, atol=1e-6 * float(np.abs(ref).max()))   # off-diagonals cancel
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_l1_ssim_loss_vs_reference(orc, tag):
+    """N3: utils/loss_utils.py l1_loss/ssim and torch.autograd's gradient of finetune.py:48's loss."""
+    d = _load("loss.npz")
+    loss, l1, ss, g = orc.l1_ssim(d[f"img_{tag}"], d[f"gt_{tag}"], 0.2)
+    assert abs(loss - float(d[f"loss_{tag}"])) < 2e-6
+    assert abs(ss - float(d[f"ssim_{tag}"])) < 2e-6 and abs(l1 - float(d[f"l1_{tag}"])) < 1e-6
+    ref = d[f"grad_{tag}"]
+    assert np.abs(g - ref).max() / np.abs(ref).max() < 2e-5
