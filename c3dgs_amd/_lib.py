@@ -71,6 +71,8 @@ PROTOTYPES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c3dgs_vq_apply": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_int32, C.c_void_p]),
+    "c3dgs_morton_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "c3dgs_morton_order": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c3dgs_l1_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
     "c3dgs_l1_ssim_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -28,6 +28,7 @@ SOURCES = {
     "render.hip": os.environ.get("C3DGS_RENDER_FLAGS", "-fno-slp-vectorize").split(),
     "vq.hip": [],
     "loss.hip": [],
+    "encode.hip": [],
 }
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gsmath.hpp"),
            os.path.join(HERE, "..", "include", "c3dgs_hip.h")]

@@ -348,6 +348,18 @@ int c3dgs_vq_apply(int32_t K, int32_t D, const float* S, float* codebook, float*
     return C3DGS_OK;
 }
 
+size_t c3dgs_morton_workspace_bytes(int32_t P) { return morton_workspace_bytes(P); }
+
+int c3dgs_morton_order(int32_t P, const float* xyz, int64_t* codes, int64_t* order, void* workspace, void* stream)
+{
+    if (P < 0) return fail(C3DGS_E_INVALID, "P must be >= 0");
+    if (P == 0) return C3DGS_OK;
+    if (!xyz || !codes || !order || !workspace) return fail(C3DGS_E_INVALID, "morton_order: bad arguments");
+    if (run_morton_order(P, xyz, codes, order, workspace, (hipStream_t)stream)) return fail(C3DGS_E_HIP, "morton_order failed");
+    C3DGS_STAGE("morton_order", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
 int c3dgs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, float* dmaps, double* sums,
                           void* stream)
 {

@@ -165,6 +165,9 @@ void launch_vq_accumulate(int64_t B, int K, int D, const float* x, const float* 
 void launch_vq_apply(int K, int D, const float* S, float* codebook, float* entry_importance, float decay, float alpha,
                      float eps, int scale_normalize, hipStream_t s);
 
+// encode.hip
+size_t morton_workspace_bytes(int P);
+int run_morton_order(int P, const float* xyz, int64_t* codes_out, int64_t* order_out, void* workspace, hipStream_t s);
 // loss.hip
 void launch_l1_ssim_forward(int C, int H, int W, const float* img, const float* gt, float* Dmu, float* Ds1, float* Ds12,
                             double* sums, hipStream_t s);

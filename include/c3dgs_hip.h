@@ -155,6 +155,13 @@ int c3dgs_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img, co
                            const float* grad_loss /*device [1]*/, float l1_coeff, float ssim_coeff, float* dL_dimg,
                            void* stream);
 
+/* ---- Morton ordering (reference GaussianModel._sort_morton, scene/gaussian_model.py:997-1003,
+ * mortonEncode :1417-1432).  codes[i] = 63-bit Morton code of xyz[i] (21 bits per axis, axes in ascending-extent order),
+ * order = ids sorted stably by code (int64, usable as a torch index). workspace: c3dgs_morton_workspace_bytes(P). */
+size_t c3dgs_morton_workspace_bytes(int32_t P);
+int c3dgs_morton_order(int32_t P, const float* xyz /*[P,3]*/, int64_t* codes /*[P]*/, int64_t* order /*[P]*/,
+                       void* workspace, void* stream);
+
 /* ---- introspection (tests and profiling only) ---- */
 typedef struct c3dgs_geom_layout {   /* byte offsets into the geometry buffer for P Gaussians */
     size_t total_bytes;

@@ -921,3 +921,43 @@ void orc_l1_ssim(int C, int H, int W, const float* img, const float* gt, double 
     }
     free(Dmu); free(Ds1); free(Ds12);
 }
+
+/* ---------------------------------------------------------------- N4: Morton order (scene/gaussian_model.py:997-1003, 1417-1432)
+ * xyz_q = ((2^21-1) * (xyz - min) / (max - min)).long()  in fp32, axes ordered by ascending extent
+ * (pp_diap.argsort()), 21-bit interleave x | y<<1 | z<<2, then a STABLE ascending sort of the codes. */
+static uint64_t split_by_3(uint64_t a)
+{
+    uint64_t x = a & 0x1FFFFFull;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+void orc_morton_codes(int P, const float* xyz, int64_t* codes, int32_t axis_order[3])
+{
+    float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX }, diap[3];
+    for (int i = 0; i < P; i++)
+        for (int a = 0; a < 3; a++) {
+            const float v = xyz[3 * (size_t)i + a];
+            if (v < mn[a]) mn[a] = v;
+            if (v > mx[a]) mx[a] = v;
+        }
+    for (int a = 0; a < 3; a++) diap[a] = mx[a] - mn[a];
+    /* argsort ascending (ties: lower axis first, as torch's stable CPU sort of 3 elements would give) */
+    int ord[3] = { 0, 1, 2 };
+    for (int i = 0; i < 3; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (diap[ord[j]] < diap[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    for (int a = 0; a < 3; a++) axis_order[a] = ord[a];
+    for (int i = 0; i < P; i++) {
+        uint64_t q[3];
+        for (int a = 0; a < 3; a++) {
+            const float v = 2097151.0f * (xyz[3 * (size_t)i + a] - mn[a]) / diap[a];
+            q[a] = (uint64_t)(int64_t)v;
+        }
+        codes[i] = (int64_t)(split_by_3(q[ord[0]]) | split_by_3(q[ord[1]]) << 1 | split_by_3(q[ord[2]]) << 2);
+    }
+}

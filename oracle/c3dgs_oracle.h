@@ -108,6 +108,9 @@ void orc_vq_trace_normalize(int K, int D, float* codebook);
 
 int orc_num_threads(void);
 
+/* N4: Morton codes of scene/gaussian_model.py:997-1003,1417-1432 */
+void orc_morton_codes(int P, const float* xyz, int64_t* codes, int32_t axis_order[3]);
+
 /* N3: L1 + SSIM loss of finetune.py:48 / utils/loss_utils.py:17-63 and its gradient w.r.t. img */
 void orc_l1_ssim(int C, int H, int W, const float* img, const float* gt, double lambda, double* out /*[3]*/,
                  float* dL_dimg /*[C,H,W] or NULL*/);

@@ -83,6 +83,8 @@ def lib():
         _lib.orc_test_color_from_sh.argtypes = [C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, _u8p, _f32p]
         _lib.orc_l1_ssim.restype = None
         _lib.orc_l1_ssim.argtypes = [C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_double, C.POINTER(C.c_double), _f32p]
+        _lib.orc_morton_codes.restype = None
+        _lib.orc_morton_codes.argtypes = [C.c_int, _f32p, _i64p, _i32p]
         _lib.orc_test_cov3d.restype = None
         _lib.orc_test_cov3d.argtypes = [C.c_int, _f32p, C.c_float, _f32p, _f32p]
     return _lib
@@ -354,3 +356,18 @@ def l1_ssim(img, gt, lambda_dssim=0.2, want_grad=True):
     g = np.zeros_like(img) if want_grad else None
     lib().orc_l1_ssim(Cc, H, W, _p(img, _f32p), _p(gt, _f32p), float(lambda_dssim), out, _p(g, _f32p))
     return float(out[0]), float(out[1]), float(out[2]), g
+
+
+# ----------------------------------------------------------------------------- N4: Morton order
+def morton_codes(xyz):
+    """(codes int64[P], axis order int32[3]) as GaussianModel._sort_morton computes them before sorting."""
+    xyz = _f32(xyz).reshape(-1, 3)
+    codes = np.zeros(xyz.shape[0], np.int64)
+    order = np.zeros(3, np.int32)
+    lib().orc_morton_codes(xyz.shape[0], _p(xyz, _f32p), _p(codes, _i64p), _p(order, _i32p))
+    return codes, order
+
+
+def morton_order(xyz):
+    codes, _ = morton_codes(xyz)
+    return np.argsort(codes, kind="stable")

@@ -10,6 +10,7 @@ What it pins; the fixtures hold data only (inputs + exp
   sh.npz         utils/sh_utils.py:eval_sh                       -> K2's SH->RGB (before +0.5 / clamp)
   cov3d.npz      utils/general_utils.py:build_covariance_from_scaling_rotation -> K2's cov3D
   loss.npz       utils/loss_utils.py: (1-l)*l1_loss + l*(1-ssim) and its autograd gradient (finetune.py:48)
+  morton.npz     mortonEncode/splitBy3 (scene/gaussian_model.py:1417-1432) on _sort_morton's quantisation (:999-1003)
   camgrad.npz    the closed-form grad_params block of _RasterizeGaussiansIndexedCamera.backward
                  (diff_gaussian_rasterization_no_camera/__init__.py:674-844), executed on CPU tensors
 """
@@ -140,6 +141,24 @@ def gen_camgrad():
     print("camgrad.npz")
 
 
+def gen_morton():
+    """mortonEncode / splitBy3 (scene/gaussian_model.py:1417-1432) executed on the quantised positions of
+    _sort_morton (:999-1003). The module itself is not importable (simple_knn, plyfile), the two functions are
+    self-contained, so their text is executed here."""
+    src = open(os.path.join(REF, "scene/gaussian_model.py")).read().split("\n")
+    ns = dict(torch=torch)
+    exec("\n".join(src[1416:1432]), ns)
+    g = torch.Generator().manual_seed(4)
+    xyz = (torch.randn(5000, 3, generator=g) * torch.tensor([3.0, 0.7, 1.9])).float()
+    pp_min = xyz.min(0).values
+    pp_diap = xyz.max(0).values - pp_min
+    xyz_q = ((2 ** 21 - 1) * (xyz - pp_min) / pp_diap).long()
+    codes = ns["mortonEncode"](xyz_q, pp_diap.argsort())
+    np.savez_compressed(os.path.join(OUT, "morton.npz"), xyz=xyz.numpy(), codes=codes.numpy().astype(np.int64),
+                        axis_order=pp_diap.argsort().numpy().astype(np.int32))
+    print("morton.npz")
+
+
 def gen_loss():
     """finetune.py:48 loss and its autograd gradient, utils/loss_utils.py (pure torch, importable)."""
     from utils.loss_utils import l1_loss, ssim
@@ -168,3 +187,4 @@ if __name__ == "__main__":
     gen_cov3d()
     gen_camgrad()
     gen_loss()
+    gen_morton()

@@ -55,3 +55,13 @@ def test_l1_ssim_loss_vs_reference(orc, tag):
     assert abs(ss - float(d[f"ssim_{tag}"])) < 2e-6 and abs(l1 - float(d[f"l1_{tag}"])) < 1e-6
     ref = d[f"grad_{tag}"]
     assert np.abs(g - ref).max() / np.abs(ref).max() < 2e-5
+
+
+def test_morton_codes_vs_reference(orc):
+    """N4: bit-exact Morton codes (integer work) against the reference's mortonEncode on the same points."""
+    d = _load("morton.npz")
+    codes, order = orc.morton_codes(d["xyz"])
+    np.testing.assert_array_equal(order, d["axis_order"])
+    np.testing.assert_array_equal(codes, d["codes"])
+    perm = orc.morton_order(d["xyz"])
+    assert np.all(np.diff(codes[perm]) >= 0) and sorted(perm.tolist()) == list(range(len(codes)))
