@@ -4,6 +4,9 @@ Drop-in for the reference's two native extensions and the Python directly around
 
     c3dgs_amd.rasterizer  <->  diff_gaussian_rasterization_no_camera (and its two sibling packages)
     c3dgs_amd.vq          <->  weighted_distance._C.weightedDistance + compression/vq.py
+    c3dgs_amd.loss        <->  utils/loss_utils.py (l1_loss, ssim) + the fused QAT loss of finetune.py:48
+    c3dgs_amd.sensitivity <->  compress.py:calc_importance_experimental (camera-sharded)
+    c3dgs_amd.encode      <->  GaussianModel._sort_morton / mortonEncode
 
 The numeric work runs in c3dgs_amd/libc3dgs_hip.so (include/c3dgs_hip.h); build it with
 `python -m c3dgs_amd.build`.  There is no CPU fallback.
@@ -11,12 +14,15 @@ The numeric work runs in c3dgs_amd/libc3dgs_hip.so (include/c3dgs_hip.h); build 
 import sys
 import types
 
-from . import rasterizer, vq  # noqa: F401
+from . import encode, loss, rasterizer, sensitivity, vq  # noqa: F401
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, GaussianRasterizerIndexed,  # noqa: F401
                          getProjectionMatrix, mat_to_quat, quat_to_mat, rasterize_gaussians,
                          rasterize_gaussians_indexed, rasterize_gaussians_indexed_camera)
 from .vq import (CompressionSettings, VectorQuantize, compress_color, compress_covariance, compress_gaussians,  # noqa: F401
                  join_features, vq_features, weightedDistance)
+
+from .loss import l1_loss, l1_ssim_loss, ssim  # noqa: F401,E402
+from .encode import morton_codes, morton_order  # noqa: F401,E402
 
 __version__ = "0.1.0"
 
