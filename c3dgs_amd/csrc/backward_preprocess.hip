@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
     __shared__ int64_t s_gi[INDEXED ? 256 : 1];
     if (INDEXED) { s_row[threadIdx.x] = -1; s_gi[threadIdx.x] = -1; }
 
-    const bool live = i < a.P && a.radii[i] > 0;
+    bool live = i < a.P && a.radii[i] > 0;
 
     // ---- (a) sum each Gaussian's per-tile partials: slots [start, end) of inst_offset (id order, so the 64
     // Gaussians of a wave own ONE contiguous slot range). A per-lane loop over global memory would run as long as
@@ -142,6 +142,8 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
     // and every lane then adds up its own run from LDS. Fixed order -> still bitwise reproducible.
     constexpr int CH = 128;
     __shared__ float s_stage[4][CH][PARTIAL_FLOATS];
+    __shared__ uint8_t s_wr[4][CH];
+    bool any_written = false;            // did ANY pixel of ANY tile blend this Gaussian?
     float acc[PARTIAL_FLOATS];
 #pragma unroll
     for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] = 0.f;
@@ -163,6 +165,7 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
                     const float* src = a.partials + (size_t)(c0 + sl) * PARTIAL_FLOATS;
 #pragma unroll
                     for (int q = 0; q < PARTIAL_FLOATS; q++) s_stage[wv][sl][q] = wr ? src[q] : 0.f;
+                    s_wr[wv][sl] = wr ? 1 : 0;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -172,12 +175,18 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
             for (uint32_t sl = lo; sl < hi; sl++) {
 #pragma unroll
                 for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] += s_stage[wv][sl - c0][q];
+                any_written |= s_wr[wv][sl - c0] != 0;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (i < a.P && !live) {                // culled: the reference leaves its zero-filled rows untouched
+    // A Gaussian none of whose tile instances was ever blended (it sits behind every pixel's saturation point: the
+    // majority on dense scenes) has exactly zero gradients: it takes the cheap zero-fill path, i.e. no SH / codebook
+    // gathers, no scatter-adds. Same values as the reference, which adds nothing for it.
+    const bool live_in = live;
+    live = live_in && any_written;
+    if (i < a.P && !live) {                // culled or never blended: all-zero gradient rows
         if (o.dL_dmeans2D) { o.dL_dmeans2D[3 * si] = 0.f; o.dL_dmeans2D[3 * si + 1] = 0.f; o.dL_dmeans2D[3 * si + 2] = 0.f; }
         if (o.dL_dcolors) { o.dL_dcolors[3 * si] = 0.f; o.dL_dcolors[3 * si + 1] = 0.f; o.dL_dcolors[3 * si + 2] = 0.f; }
         if (o.dL_dopacity) o.dL_dopacity[si] = 0.f;
