@@ -135,3 +135,20 @@ def test_full_hd_properties(hip):
     for k, v in g.items():
         assert np.isfinite(v).all(), k
     assert np.abs(g["dL_dmeans3D"]).max() > 0
+
+
+def test_debug_and_prefiltered_flags(hip, orc):
+    """debug=True synchronises after every stage (reference CHECK_CUDA) and changes no result; prefiltered=True skips
+    the near-plane test (auxiliary.h:146-147), which is a no-op on a scene that is entirely in front of the camera."""
+    from c3dgs_amd import rasterizer as rz
+    inp, cam, _ = cases.make_case("base")
+    fw0 = gpu_util.hip_forward(inp, cam, False)
+    a = list(fw0["args"])
+    a[-2] = True                                    # debug
+    out_dbg = rz._C.rasterize_gaussians(*a)
+    assert out_dbg[0] == fw0["num_rendered"] and torch.equal(out_dbg[1], fw0["color"]) and torch.equal(out_dbg[2], fw0["radii"])
+    a[-2], a[-3] = False, True                      # prefiltered
+    out_pre = rz._C.rasterize_gaussians(*a)
+    assert torch.equal(out_pre[1], fw0["color"]) and torch.equal(out_pre[2], fw0["radii"])
+    g0 = gpu_util.hip_backward(fw0, synth.grad_image(cam["W"], cam["H"]).numpy())
+    assert all(np.isfinite(v).all() for v in g0.values())
