@@ -137,6 +137,40 @@ class VectorQuantize(nn.Module):
         return self.codebook[idx], idx
 
 
+class _BatchDraws:
+    """The `torch.randint(0, N, [chunk])` draws of vq.py:69, prefetched. A single randint of k*chunk numbers consumes the
+    CPU generator exactly like k consecutive draws of `chunk` (torch's CPU kernel is serial), so blocks of steps are drawn
+    at once on a helper thread, in order, and handed over through a small queue."""
+
+    def __init__(self, N, chunk, steps, device, device_rng=False, block_bytes=64 << 20):
+        import queue
+        import threading
+        self.N, self.chunk, self.steps, self.device, self.device_rng = N, chunk, steps, device, device_rng
+        self.buf, self.pos = None, 0
+        if device_rng or steps <= 0:
+            return
+        per_block = max(1, min(steps, block_bytes // (8 * max(chunk, 1))))
+        self.q = queue.Queue(maxsize=2)
+
+        def produce():
+            left = steps
+            while left > 0:
+                k = min(per_block, left)
+                self.q.put(torch.randint(low=0, high=N, size=[k * chunk]))
+                left -= k
+        self.thread = threading.Thread(target=produce, daemon=True)
+        self.thread.start()
+
+    def next(self):
+        if self.device_rng:
+            return torch.randint(low=0, high=self.N, size=[self.chunk], device=self.device)
+        if self.buf is None or self.pos >= self.buf.numel():
+            self.buf, self.pos = self.q.get().to(self.device), 0
+        out = self.buf[self.pos:self.pos + self.chunk]
+        self.pos += self.chunk
+        return out
+
+
 def _dist_info(group):
     import torch.distributed as dist
     if group is None or not dist.is_available() or not dist.is_initialized():
@@ -148,10 +182,13 @@ def _dist_info(group):
 def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size: int, vq_chunk: int = 2 ** 16,
                 steps: int = 1000, decay: float = 0.8, scale_normalize: bool = False, silent: bool = False,
                 group=None, batches=None, init_rand: Optional[torch.Tensor] = None, return_errors: bool = False,
-                shard_final: bool = True, ops=None) -> Tuple[torch.Tensor, torch.Tensor]:
+                shard_final: bool = True, ops=None, device_rng: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """compression/vq.py:49-87.  group=None: single GPU.  group=True (default process group) or a
     ProcessGroup: sharded Lloyd steps with one all-reduce of S[K, D+1] per step.
-    The per-step `.item()` host sync of the reference (vq.py:71) is deferred to the end."""
+    The per-step `.item()` host sync of the reference (vq.py:71) is deferred to the end.
+    Batch indices: by default the reference's draws exactly -- `torch.randint` on the CPU default generator (vq.py:69);
+    they are produced a few steps ahead on a helper thread (one block draw == the same stream as per-step draws) so the
+    GPU does not wait for the host RNG. device_rng=True draws on the GPU instead (faster, different numbers)."""
     dist, rank, world = _dist_info(group)
     pg = None if group is True else group
     dev = features.device
@@ -167,15 +204,14 @@ def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size:
     imp = importance_n.detach().contiguous().float()
     err_sums = []
     it = range(steps) if batches is None else range(len(batches))
+    draws = None if batches is not None else _BatchDraws(N, vq_chunk, steps, dev, device_rng)
     for s in it:
         if batches is not None:
             batch = batches[s].to(device=dev, dtype=torch.int64)
         else:
-            batch = torch.randint(low=0, high=N, size=[vq_chunk])                   # CPU RNG, as vq.py:69
+            batch = draws.next()
             if world > 1:                                                           # every rank uses rank 0's draw
-                batch = batch.to(dev)
                 dist.broadcast(batch, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
-            batch = batch.to(dev)
         B = int(batch.numel())
         lo, hi = (rank * B) // world, ((rank + 1) * B) // world
         with torch.no_grad():

@@ -94,3 +94,14 @@ def test_install_as_reference_modules():
     for n in ("diff_gaussian_rasterization_no_camera", "diff_gaussian_rasterization", "diff_gaussian_rasterization_camera",
               "weighted_distance", "weighted_distance._C"):
         sys.modules.pop(n, None)
+
+
+def test_prefetched_batch_draws_equal_reference_stream():
+    """vq.py:69 draws `torch.randint(0, N, [chunk])` once per step on the CPU generator; the helper thread draws blocks of
+    steps at once, which must consume the generator identically."""
+    from c3dgs_amd.vq import _BatchDraws
+    torch.manual_seed(3)
+    ref = [torch.randint(low=0, high=1000, size=[37]) for _ in range(11)]
+    torch.manual_seed(3)
+    d = _BatchDraws(1000, 37, 11, "cpu", block_bytes=37 * 8 * 4)
+    assert all(torch.equal(a, d.next()) for a in ref)
