@@ -138,37 +138,18 @@ class VectorQuantize(nn.Module):
 
 
 class _BatchDraws:
-    """The `torch.randint(0, N, [chunk])` draws of vq.py:69, prefetched. A single randint of k*chunk numbers consumes the
-    CPU generator exactly like k consecutive draws of `chunk` (torch's CPU kernel is serial), so blocks of steps are drawn
-    at once on a helper thread, in order, and handed over through a small queue."""
+    """The batch indices of one Lloyd step. Default: exactly the reference's draw -- `torch.randint(0, N, [chunk])` on the
+    CPU default generator (vq.py:69) -- issued inline: the GPU work of the previous step runs asynchronously underneath,
+    so the host RNG (about 2 ms for 2^18 draws) is the floor of a step either way (a prefetch thread was measured and is
+    slower). device_rng=True draws on the GPU instead: no host work, different numbers."""
 
-    def __init__(self, N, chunk, steps, device, device_rng=False, block_bytes=64 << 20):
-        import queue
-        import threading
-        self.N, self.chunk, self.steps, self.device, self.device_rng = N, chunk, steps, device, device_rng
-        self.buf, self.pos = None, 0
-        if device_rng or steps <= 0:
-            return
-        per_block = max(1, min(steps, block_bytes // (8 * max(chunk, 1))))
-        self.q = queue.Queue(maxsize=2)
-
-        def produce():
-            left = steps
-            while left > 0:
-                k = min(per_block, left)
-                self.q.put(torch.randint(low=0, high=N, size=[k * chunk]))
-                left -= k
-        self.thread = threading.Thread(target=produce, daemon=True)
-        self.thread.start()
+    def __init__(self, N, chunk, steps, device, device_rng=False):
+        self.N, self.chunk, self.device, self.device_rng = N, chunk, device, device_rng
 
     def next(self):
         if self.device_rng:
             return torch.randint(low=0, high=self.N, size=[self.chunk], device=self.device)
-        if self.buf is None or self.pos >= self.buf.numel():
-            self.buf, self.pos = self.q.get().to(self.device), 0
-        out = self.buf[self.pos:self.pos + self.chunk]
-        self.pos += self.chunk
-        return out
+        return torch.randint(low=0, high=self.N, size=[self.chunk]).to(self.device)
 
 
 def _dist_info(group):
@@ -187,8 +168,7 @@ def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size:
     ProcessGroup: sharded Lloyd steps with one all-reduce of S[K, D+1] per step.
     The per-step `.item()` host sync of the reference (vq.py:71) is deferred to the end.
     Batch indices: by default the reference's draws exactly -- `torch.randint` on the CPU default generator (vq.py:69);
-    they are produced a few steps ahead on a helper thread (one block draw == the same stream as per-step draws) so the
-    GPU does not wait for the host RNG. device_rng=True draws on the GPU instead (faster, different numbers)."""
+    device_rng=True draws on the GPU instead (removes the host-RNG floor of ~2 ms/step, different numbers)."""
     dist, rank, world = _dist_info(group)
     pg = None if group is True else group
     dev = features.device

@@ -96,12 +96,11 @@ def test_install_as_reference_modules():
         sys.modules.pop(n, None)
 
 
-def test_prefetched_batch_draws_equal_reference_stream():
-    """vq.py:69 draws `torch.randint(0, N, [chunk])` once per step on the CPU generator; the helper thread draws blocks of
-    steps at once, which must consume the generator identically."""
+def test_batch_draws_equal_reference_stream():
+    """vq.py:69 draws `torch.randint(0, N, [chunk])` once per step on the CPU default generator; so do we."""
     from c3dgs_amd.vq import _BatchDraws
     torch.manual_seed(3)
     ref = [torch.randint(low=0, high=1000, size=[37]) for _ in range(11)]
     torch.manual_seed(3)
-    d = _BatchDraws(1000, 37, 11, "cpu", block_bytes=37 * 8 * 4)
+    d = _BatchDraws(1000, 37, 11, "cpu")
     assert all(torch.equal(a, d.next()) for a in ref)
