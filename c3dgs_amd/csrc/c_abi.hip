@@ -134,7 +134,7 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
 
     C3DGS_HIP_TRY(hipMemsetAsync(img.ranges, 0, (size_t)T * sizeof(uint2), s));      // K7
     if (R > 0) {
-        { StageTimer t_(ST_DUPLICATE, s); launch_duplicate_with_keys(P, g, radii, b, gx, s); } // K5
+        { StageTimer t_(ST_DUPLICATE, s); launch_duplicate_with_keys(P, g, b, gx, s); } // K5
         C3DGS_STAGE("duplicate_with_keys", p.debug, s);
         const int end_bit = (int)higher_msb((uint32_t)T);                           // tile bits only (rasterizer_impl.cu:298)
         { StageTimer t_(ST_SORT, s);
@@ -145,7 +145,7 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
         C3DGS_STAGE("identify_ranges", p.debug, s);
     }
     { StageTimer t_(ST_RENDER_FWD, s);
-      launch_render_forward(W, H, img, b.point_list, g.splat, nullptr, p.background, out_color, s); } // K9
+      launch_render_forward(W, H, img, b.point_list, g.splat, p.background, out_color, s); } // K9
     C3DGS_STAGE("render_forward", p.debug, s);
     return C3DGS_OK;
 }
@@ -186,7 +186,7 @@ static int backward_impl(const c3dgs_raster_params* pp, bool indexed, const int3
     if (R > 0) {
         const BinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), R, W, H);
         { StageTimer t_(ST_RENDER_BWD, s);
-          launch_render_backward(W, H, img, b.point_list, g.splat, nullptr, p.background, dL_dout_color, partials, touched, s); } // K10
+          launch_render_backward(W, H, img, b.point_list, g.splat, p.background, dL_dout_color, partials, touched, s); } // K10
         C3DGS_STAGE("render_backward", p.debug, s);
     }
     { StageTimer t_(ST_BWD_PREPROCESS, s); launch_backward_preprocess(p, radii, g, partials, touched, *grads, s); } // K11 + K12(i)

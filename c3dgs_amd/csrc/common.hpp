@@ -138,7 +138,7 @@ inline ImgPtrs img_ptrs(void* base, int W, int H)
 // preprocess.hip
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, hipStream_t s);
-void launch_duplicate_with_keys(int P, const GeomPtrs& g, const int32_t* radii, const BinPtrs& b, int grid_x, hipStream_t s);
+void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, hipStream_t s);
 void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, hipStream_t s);
 // binning.hip
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
@@ -150,9 +150,9 @@ hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uin
                          uint32_t* vout, int R, int end_bit, hipStream_t s);
 // render.hip
 void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
-                           const float* colors_precomp, const float* bg, float* out_color, hipStream_t s);
+                           const float* bg, float* out_color, hipStream_t s);
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
-                            const float* colors_precomp, const float* bg, const float* dL_dpix, float* partials,
+                            const float* bg, const float* dL_dpix, float* partials,
                             uint8_t* touched, hipStream_t s);
 // backward_preprocess.hip
 void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* radii, const GeomPtrs& g,

@@ -87,7 +87,7 @@ morton_codes_kernel(int P, const float* __restrict__ xyz, const uint32_t* __rest
 }
 
 __global__ void __launch_bounds__(256)
-widen_kernel(int P, const uint32_t* __restrict__ in, const uint64_t* __restrict__ codes_sorted_unused, int64_t* __restrict__ out)
+widen_kernel(int P, const uint32_t* __restrict__ in, int64_t* __restrict__ out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < P) out[i] = (int64_t)in[i];
@@ -121,7 +121,7 @@ int run_morton_order(int P, const float* xyz, int64_t* codes_out, int64_t* order
     morton_codes_kernel<<<grid, 256, 0, s>>>(P, xyz, box, (uint64_t*)codes_out, ids);
     if (rocprim::radix_sort_pairs(temp, temp_bytes, (const uint64_t*)codes_out, codes_sorted, ids, ids_sorted, p, 0u, 63u, s) != hipSuccess)
         return 1;
-    widen_kernel<<<grid, 256, 0, s>>>(P, ids_sorted, codes_sorted, order_out);
+    widen_kernel<<<grid, 256, 0, s>>>(P, ids_sorted, order_out);
     return 0;
 }
 

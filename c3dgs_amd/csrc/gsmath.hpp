@@ -143,7 +143,4 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
     y1 = min(gy, max(0, (int)((py + max_radius + 16 - 1) / 16)));
 }
 
-// SH basis value for coefficient k given unit direction; used by forward (dot with coeffs) and backward.
-struct ShDir { float x, y, z, xx, yy, zz, xy, yz, xz; };
-
 } // namespace c3dgs

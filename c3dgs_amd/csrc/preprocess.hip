@@ -11,7 +11,7 @@
 // record (3 x float4) so the per-tile gathers in render.hip touch a single cache line:
 //   rec[0] = {mean2D.x, mean2D.y, conic.a, conic.b}
 //   rec[1] = {conic.c, opacity, r, g}
-//   rec[2] = {b, bits(exclusive tile-instance offset), bits(x0|y0<<16), bits(x1|y1<<16)}
+//   rec[2] = {b, bits(first backward partial-sum slot, id order), bits(x0|y0<<16), bits(x1|y1<<16)}
 // The last three words let the backward find the instance slot of (Gaussian, tile) without any
 // extra gather (see render.hip).
 #include "common.hpp"
@@ -259,7 +259,7 @@ stamp_slots_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint
     reinterpret_cast<float*>(splat + 3 * (size_t)i + 2)[1] = __uint_as_float(slot0);
 }
 
-void launch_duplicate_with_keys(int P, const GeomPtrs& g, const int32_t* /*radii*/, const BinPtrs& b, int grid_x, hipStream_t s)
+void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, hipStream_t s)
 {
     if (P <= 0) return;
     stamp_slots_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.tiles_touched, g.inst_offset, g.splat);

@@ -4,19 +4,21 @@
 //   K10  reference BACKWARD::renderCUDA  cuda_rasterizer/backward.cu:399-557
 //
 // MI355X design (not a translation of the CUDA kernels):
-//  * one 16x16 tile per 256-thread workgroup = 4 wave64; each wave owns an 8x8 pixel quadrant, so a
-//    small Gaussian usually leaves whole waves idle and they skip it with one ballot;
-//  * the tile's slice of the sorted point list is read coalesced, the 48-byte splat records are
-//    gathered one cache line each into a double-buffered LDS batch (one barrier per batch), the
-//    next batch's gather is issued before the current batch is blended;
-//  * early-out is a per-wave ballot plus four LDS flags read after the batch barrier;
+//  * one 16x16 tile per 256-thread workgroup = 4 wave64; each wave owns an 8x8 pixel quadrant;
+//  * per staged Gaussian an exact-conservative test decides which quadrants it can reach at all (minimum of the
+//    quadratic form over the quadrant rectangle vs ln(255*opacity)); the four 256-bit masks are iterated as scalar
+//    bitmasks, so a wave never spends an instruction on a Gaussian that cannot touch its pixels;
+//  * the tile's slice of the sorted point list is read coalesced, the 48-byte splat records are gathered one cache
+//    line each into a double-buffered LDS batch (one barrier per batch), the next batch's gather is issued before
+//    the current batch is blended; the forward blend is branch-free (selects), early-out is a per-wave ballot plus
+//    four LDS flags read after the batch barrier;
 //  * workgroup ids are remapped so that each XCD (own L2) gets a contiguous band of tiles;
-//  * backward: NO global atomics. The 9 per-Gaussian sums are reduced over the wave by a transposing
-//    DPP / permlane-swap network shared by 7 Gaussians, over the 4 waves through LDS, and stored once per (Gaussian, tile)
-//    instance into a slot array indexed like duplicate_with_keys' unsorted emission order; the
-//    per-Gaussian kernel (backward_preprocess.hip) then sums a contiguous run of slots. Plain
-//    stores run ~4-5x the chip-wide float-atomic rate on MI355X and the result is bitwise
-//    reproducible (the reference's 9 atomics per pixel-Gaussian pair, backward.cu:523-554, are not).
+//  * backward: NO global atomics. Per pixel only 9 raw sums (3 colour terms + 6 moments of w = G*dL/dalpha about the
+//    mean) are formed; 7 Gaussians x 9 sums are reduced over the wave together by a transposing DPP / permlane-swap
+//    network, the 4 waves are combined through LDS, and one plain 36-byte store (+ a flag byte) per (Gaussian, tile)
+//    instance goes to a slot array laid out in Gaussian-id order; the per-Gaussian kernel (backward_preprocess.hip)
+//    then sums a contiguous run of slots. Plain stores run ~4-5x the chip-wide float-atomic rate on MI355X and the
+//    result is bitwise reproducible (the reference's 9 atomics per pixel-Gaussian pair, backward.cu:523-554, are not).
 #include "common.hpp"
 
 namespace c3dgs {
@@ -150,19 +152,20 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
                 const int j = c * 64 + __builtin_ctzll(m);
                 m &= m - 1;
                 const float4 a = s_a[buf][j], b = s_b[buf][j];
+                const float cblue = s_c[buf][j];
                 float dx, dy, G, alpha;
                 const bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
-                if (hit && !done) {
-                    const float test_T = Tr * (1.f - alpha);
-                    if (test_T < 0.0001f) {
-                        done = true;             // forward.cu:355-360: stop BEFORE blending this one
-                    } else {
-                        const float w = alpha * Tr;
-                        C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(s_c[buf][j], w, C2);
-                        Tr = test_T;
-                        last_contributor = base + (uint32_t)j + 1u;
-                    }
-                }
+                // branch-free blend (selects instead of nested exec-mask regions: the loop is co-limited by the
+                // scalar unit, and every divergent `if` costs several s_and_saveexec / s_or exec instructions)
+                const bool live_px = hit && !done;
+                const float test_T = Tr * (1.f - alpha);
+                const bool stop = live_px && test_T < 0.0001f;   // forward.cu:355-360: stop BEFORE blending this one
+                const bool blend = live_px && !stop;
+                const float w = blend ? alpha * Tr : 0.f;
+                C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(cblue, w, C2);
+                Tr = blend ? test_T : Tr;
+                last_contributor = blend ? base + (uint32_t)j + 1u : last_contributor;
+                done = done || stop;
                 if (__all(done)) { wave_all_done = true; break; }
             }
         }
@@ -182,7 +185,7 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
 }
 
 void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
-                           const float* /*colors_precomp*/, const float* bg, float* out_color, hipStream_t s)
+                           const float* bg, float* out_color, hipStream_t s)
 {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     const int grid = ((T + 7) / 8) * 8;
@@ -423,7 +426,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
 }
 
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
-                            const float* /*colors_precomp*/, const float* bg, const float* dL_dpix, float* partials,
+                            const float* bg, const float* dL_dpix, float* partials,
                             uint8_t* touched, hipStream_t s)
 {
     const int gx = tiles_x(W), T = gx * tiles_y(H);

@@ -46,7 +46,7 @@ weighted_distance_kernel(int64_t N, int C, const float* __restrict__ coefs, cons
         const V* src = reinterpret_cast<const V*>(coefs + row * K);
 #pragma unroll
         for (int q = 0; q < KV; q++) {
-            const V v = (N > 0) ? src[q] : V{};
+            const V v = src[q];
             const float* f = reinterpret_cast<const float*>(&v);
 #pragma unroll
             for (int e = 0; e < VN; e++) x[p][q * VN + e] = f[e];
