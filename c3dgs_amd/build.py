@@ -29,6 +29,7 @@ SOURCES = {
     "vq.hip": [],
     "loss.hip": [],
     "encode.hip": [],
+    "qat.hip": ["-ffp-contract=off"],
 }
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gsmath.hpp"),
            os.path.join(HERE, "..", "include", "c3dgs_hip.h")]

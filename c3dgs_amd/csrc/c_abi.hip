@@ -14,11 +14,13 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 // Disabled by default: zero cost. When enabled, every stage launch is bracketed by two events; nothing
 // synchronises until c3dgs_profile_read().
 enum Stage { ST_MARK_VISIBLE, ST_PREPROCESS, ST_DEPTH_SORT, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_ZERO_PARTIALS,
-             ST_RENDER_BWD, ST_BWD_PREPROCESS, ST_WDIST, ST_VQ_ACC, ST_VQ_APPLY, ST_LOSS_FWD, ST_LOSS_BWD, ST_COUNT };
+             ST_RENDER_BWD, ST_BWD_PREPROCESS, ST_WDIST, ST_VQ_ACC, ST_VQ_APPLY, ST_LOSS_FWD, ST_LOSS_BWD,
+             ST_QAT_OBSERVE, ST_QAT_CODEBOOKS, ST_QAT_VISIBLE, ST_QAT_POINTS, ST_QAT_POINTS_BWD, ST_QAT_CODEBOOKS_BWD, ST_COUNT };
 static const char* kStageNames[ST_COUNT] = { "mark_visible", "preprocess", "depth_sort", "scan", "duplicate_with_keys", "sort",
                                              "identify_ranges", "render_forward", "zero_partials", "render_backward",
                                              "backward_preprocess", "weighted_distance", "vq_accumulate", "vq_apply", "l1_ssim_forward",
-                                             "l1_ssim_backward" };
+                                             "l1_ssim_backward", "qat_observe", "qat_codebooks", "qat_visible", "qat_points",
+                                             "qat_points_backward", "qat_codebooks_backward" };
 struct ProfRec { int stage; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -387,6 +389,125 @@ int c3dgs_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img, co
         launch_l1_ssim_backward(C, H, W, img, gt, dmaps, dmaps + n, dmaps + 2 * n, grad_loss, l1_coeff, ssim_coeff, dL_dimg, s);
     }
     C3DGS_STAGE("l1_ssim_backward", 0, s);
+    return C3DGS_OK;
+}
+
+// ---- QAT getters ----
+static int qat_validate(const c3dgs_qat_params* q, const char* who)
+{
+    if (!q) return fail(C3DGS_E_INVALID, std::string(who) + ": params is NULL");
+    if (q->P < 0 || q->GS < 0 || q->SHS < 0 || q->M < 1) return fail(C3DGS_E_INVALID, std::string(who) + ": bad sizes");
+    if (!q->state) return fail(C3DGS_E_INVALID, std::string(who) + ": state is required");
+    if (q->features_dc && q->M > 1 && !q->features_rest)
+        return fail(C3DGS_E_INVALID, std::string(who) + ": features_rest is required with features_dc when M > 1");
+    if (reinterpret_cast<uintptr_t>(q->rotation) & 15) return fail(C3DGS_E_INVALID, std::string(who) + ": rotation must be 16-byte aligned");
+    return C3DGS_OK;
+}
+static bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+
+size_t c3dgs_qat_workspace_bytes(void) { return qat_workspace_bytes(); }
+size_t c3dgs_qat_scan_bytes(int32_t P) { return qat_scan_bytes(P); }
+
+int c3dgs_qat_observe(const c3dgs_qat_params* q, void* workspace, void* stream)
+{
+    if (int rc = qat_validate(q, "qat_observe")) return rc;
+    if (!workspace) return fail(C3DGS_E_INVALID, "qat_observe: workspace is required");
+    { StageTimer t_(ST_QAT_OBSERVE, (hipStream_t)stream); launch_qat_observe(*q, workspace, (hipStream_t)stream); }
+    C3DGS_STAGE("qat_observe", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_qat_codebooks(const c3dgs_qat_params* q, float* scales_n, float* rotations, float* shs, void* stream)
+{
+    if (int rc = qat_validate(q, "qat_codebooks")) return rc;
+    if (misaligned16(rotations) || misaligned16(shs)) return fail(C3DGS_E_INVALID, "qat_codebooks: outputs must be 16-byte aligned");
+    { StageTimer t_(ST_QAT_CODEBOOKS, (hipStream_t)stream); launch_qat_codebooks(*q, scales_n, rotations, shs, (hipStream_t)stream); }
+    C3DGS_STAGE("qat_codebooks", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_qat_codebooks_backward(const c3dgs_qat_params* q, const float* dL_dscales_n, const float* dL_drotations,
+                                 const float* dL_dshs, float* dL_dscaling, float* dL_drotation, float* dL_dfeatures_dc,
+                                 float* dL_dfeatures_rest, void* stream)
+{
+    if (int rc = qat_validate(q, "qat_codebooks_backward")) return rc;
+    if (misaligned16(dL_drotations) || misaligned16(dL_drotation) || misaligned16(dL_dshs))
+        return fail(C3DGS_E_INVALID, "qat_codebooks_backward: rotation / sh gradients must be 16-byte aligned");
+    if (dL_dshs && q->features_dc && (!dL_dfeatures_dc || (q->M > 1 && !dL_dfeatures_rest)))
+        return fail(C3DGS_E_INVALID, "qat_codebooks_backward: dL_dfeatures_dc / dL_dfeatures_rest are required with dL_dshs");
+    {
+        StageTimer t_(ST_QAT_CODEBOOKS_BWD, (hipStream_t)stream);
+        launch_qat_codebooks_backward(*q, dL_dscales_n, dL_drotations, dL_dshs, dL_dscaling, dL_drotation, dL_dfeatures_dc,
+                                      dL_dfeatures_rest, (hipStream_t)stream);
+    }
+    C3DGS_STAGE("qat_codebooks_backward", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_qat_visible(const c3dgs_qat_params* q, const float* viewmatrix, uint8_t* visible, int32_t* rank, int32_t* count,
+                      void* scan_workspace, void* stream)
+{
+    if (int rc = qat_validate(q, "qat_visible")) return rc;
+    if (!count) return fail(C3DGS_E_INVALID, "qat_visible: count is required");
+    hipStream_t s = (hipStream_t)stream;
+    if (q->P == 0) { C3DGS_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t), s)); return C3DGS_OK; }
+    if (!q->xyz || !viewmatrix || !visible || !rank || !scan_workspace) return fail(C3DGS_E_INVALID, "qat_visible: bad arguments");
+    { StageTimer t_(ST_QAT_VISIBLE, s); C3DGS_HIP_TRY(run_qat_visible(*q, viewmatrix, visible, rank, count, scan_workspace, s)); }
+    C3DGS_STAGE("qat_visible", 0, s);
+    return C3DGS_OK;
+}
+
+int c3dgs_qat_points(const c3dgs_qat_params* q, const uint8_t* visible, const int32_t* rank, const int64_t* sh_indices,
+                     const int64_t* g_indices, float* means3D, float* opacities, float* scale_factors, int64_t* sh_indices_out,
+                     int64_t* g_indices_out, void* stream)
+{
+    if (int rc = qat_validate(q, "qat_points")) return rc;
+    if ((visible == nullptr) != (rank == nullptr)) return fail(C3DGS_E_INVALID, "qat_points: visible and rank go together");
+    {
+        StageTimer t_(ST_QAT_POINTS, (hipStream_t)stream);
+        launch_qat_points(*q, visible, rank, sh_indices, g_indices, means3D, opacities, scale_factors, sh_indices_out,
+                          g_indices_out, (hipStream_t)stream);
+    }
+    C3DGS_STAGE("qat_points", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_qat_points_backward(const c3dgs_qat_params* q, const uint8_t* visible, const int32_t* rank, const float* dL_dmeans3D,
+                              const float* dL_dmeans2D, const float* dL_dopacities, const float* dL_dscale_factors,
+                              float* dL_dxyz, float* dL_dscreenspace, float* dL_dopacity, float* dL_dscaling_factor, void* stream)
+{
+    if (int rc = qat_validate(q, "qat_points_backward")) return rc;
+    if ((visible == nullptr) != (rank == nullptr)) return fail(C3DGS_E_INVALID, "qat_points_backward: visible and rank go together");
+    if ((dL_dopacity && dL_dopacities && !q->opacity) || (dL_dscaling_factor && dL_dscale_factors && !q->scaling_factor))
+        return fail(C3DGS_E_INVALID, "qat_points_backward: the raw opacity / scaling_factor are needed to recompute the masks");
+    {
+        StageTimer t_(ST_QAT_POINTS_BWD, (hipStream_t)stream);
+        launch_qat_points_backward(*q, visible, rank, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dscale_factors, dL_dxyz,
+                                   dL_dscreenspace, dL_dopacity, dL_dscaling_factor, (hipStream_t)stream);
+    }
+    C3DGS_STAGE("qat_points_backward", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_fake_quantize(int64_t n, const float* x, c3dgs_fq_state* state, int32_t observe, int32_t enabled,
+                        float averaging_constant, float* out, void* workspace, void* stream)
+{
+    if (n < 0) return fail(C3DGS_E_INVALID, "fake_quantize: n must be >= 0");
+    if (n == 0) return C3DGS_OK;
+    if (!x || !state || !out || (observe && !workspace)) return fail(C3DGS_E_INVALID, "fake_quantize: bad arguments");
+    launch_fake_quantize(n, x, state, observe, enabled, averaging_constant, out, workspace, (hipStream_t)stream);
+    C3DGS_STAGE("fake_quantize", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_fake_quantize_backward(int64_t n, const float* x, const c3dgs_fq_state* state, int32_t enabled, const float* g,
+                                 float* dx, void* stream)
+{
+    if (n < 0) return fail(C3DGS_E_INVALID, "fake_quantize_backward: n must be >= 0");
+    if (n == 0) return C3DGS_OK;
+    if (!x || !state || !g || !dx) return fail(C3DGS_E_INVALID, "fake_quantize_backward: bad arguments");
+    launch_fake_quantize_backward(n, x, state, enabled, g, dx, (hipStream_t)stream);
+    C3DGS_STAGE("fake_quantize_backward", 0, (hipStream_t)stream);
     return C3DGS_OK;
 }
 

@@ -175,4 +175,24 @@ void launch_l1_ssim_backward(int C, int H, int W, const float* img, const float*
                              const float* Ds12, const float* grad_loss, float l1_coeff, float ssim_coeff, float* dL_dimg,
                              hipStream_t s);
 
+// qat.hip
+size_t qat_workspace_bytes();
+size_t qat_scan_bytes(int P);
+void launch_qat_observe(const c3dgs_qat_params& q, void* workspace, hipStream_t s);
+void launch_qat_codebooks(const c3dgs_qat_params& q, float* scales_n, float* rotations, float* shs, hipStream_t s);
+void launch_qat_codebooks_backward(const c3dgs_qat_params& q, const float* g_scales, const float* g_rot, const float* g_shs,
+                                   float* d_scaling, float* d_rotation, float* d_dc, float* d_rest, hipStream_t s);
+hipError_t run_qat_visible(const c3dgs_qat_params& q, const float* view, uint8_t* visible, int32_t* rank, int32_t* count,
+                           void* scan_ws, hipStream_t s);
+void launch_qat_points(const c3dgs_qat_params& q, const uint8_t* visible, const int32_t* rank, const int64_t* sh_idx,
+                       const int64_t* g_idx, float* means3D, float* opac, float* sfac, int64_t* sh_out, int64_t* g_out,
+                       hipStream_t s);
+void launch_qat_points_backward(const c3dgs_qat_params& q, const uint8_t* visible, const int32_t* rank, const float* g_m3,
+                                const float* g_m2, const float* g_op, const float* g_sf, float* d_xyz, float* d_screen,
+                                float* d_op, float* d_sf, hipStream_t s);
+void launch_fake_quantize(long long n, const float* x, c3dgs_fq_state* state, int observe, int enabled, float c, float* out,
+                          void* workspace, hipStream_t s);
+void launch_fake_quantize_backward(long long n, const float* x, const c3dgs_fq_state* state, int enabled, const float* g,
+                                   float* dx, hipStream_t s);
+
 } // namespace c3dgs

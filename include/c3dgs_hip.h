@@ -162,6 +162,80 @@ size_t c3dgs_morton_workspace_bytes(int32_t P);
 int c3dgs_morton_order(int32_t P, const float* xyz /*[P,3]*/, int64_t* codes /*[P]*/, int64_t* order /*[P]*/,
                        void* workspace, void* stream);
 
+/* ---- QAT getters: activation + fake-quant + visibility gathers in front of every raster call -------------------
+ * SURVEY.md 8(f) row N1; reference scene/gaussian_model.py:54-77 (activations), :109-118 (seven
+ * torch.ao.quantization.FakeQuantize(dtype=qint8) modules = MovingAverageMinMaxObserver, per-tensor affine,
+ * [-128,127], averaging constant 0.01), :213-267 (getters), :851-862 (the [visible] gathers of GaussianModel.render),
+ * :1405-1414 (FakeQuantizationHalf). The reference spends ~100 small launches and ~20 host syncs per view here
+ * (aminmax + `float(scale)` / `int(zero_point)` per module, nonzero per boolean-mask gather); this path keeps the
+ * observer state on the device and never reads it back.
+ *
+ * Observer/quantiser state of ONE FakeQuantize module, resident in device memory (16 bytes): */
+typedef struct c3dgs_fq_state {
+    float min_val, max_val;   /* MovingAverageMinMaxObserver running range; +inf / -inf before the first batch */
+    float scale;              /* max((max(max_val,0) - min(min_val,0)) / 255, eps_f32)                          */
+    int32_t zero_point;       /* clamp(-128 - round(min(min_val,0)/scale), -128, 127)                           */
+} c3dgs_fq_state;
+
+enum { C3DGS_FQ_OPACITY = 0, C3DGS_FQ_SCALING = 1, C3DGS_FQ_SCALING_FACTOR = 2, C3DGS_FQ_ROTATION = 3,
+       C3DGS_FQ_FEATURES_DC = 4, C3DGS_FQ_FEATURES_REST = 5, C3DGS_FQ_COUNT = 6 };
+
+typedef struct c3dgs_qat_params {
+    int32_t P, GS, SHS, M;          /* points, geometry codebook rows, colour codebook rows, SH coefficients (M >= 1) */
+    const float* xyz;               /* [P,3]   raw _xyz                                            */
+    const float* opacity;           /* [P,1]   raw _opacity (pre-sigmoid)                          */
+    const float* scaling_factor;    /* [P,1]   raw _scaling_factor (log)                           */
+    const float* scaling;           /* [GS,3]  raw _scaling                                        */
+    const float* rotation;          /* [GS,4]  raw _rotation                                       */
+    const float* features_dc;       /* [SHS,1,3]                                                   */
+    const float* features_rest;     /* [SHS,M-1,3] (may be NULL when M == 1)                       */
+    c3dgs_fq_state* state;          /* device, [C3DGS_FQ_COUNT]                                    */
+    int32_t observer_enabled[6];    /* torch FakeQuantize.observer_enabled per module              */
+    int32_t fake_quant_enabled[6];  /* torch FakeQuantize.fake_quant_enabled per module            */
+    int32_t half_xyz;               /* 1: xyz_qa = x.half().float() (:1405-1414); 0: identity      */
+    float averaging_constant;       /* 0.01                                                        */
+} c3dgs_qat_params;
+
+/* Any input pointer may be NULL: that tensor is skipped in every call below.
+ * observe: one pass over the raw tensors -> min/max of the ACTIVATED values (sigmoid(opacity), normalize(relu(scaling)),
+ *   the rest raw), moving-average update and qparams of every module whose observer is enabled (FakeQuantize.forward,
+ *   first half). `workspace` >= c3dgs_qat_workspace_bytes() bytes of device scratch.
+ * codebooks: scales_n[GS,3] = fq(normalize(relu(scaling))); rotations[GS,4] = normalize(fq(rotation));
+ *   shs[SHS,M,3] = cat(fq_dc(features_dc), fq_rest(features_rest), dim=1)   (get_scaling_normalized,
+ *   _rotation_post_activation, _get_features_raw).
+ * visible: visible[p] = in_frustum(xyz_qa(xyz[p])) (rasterizer markVisible on get_xyz), rank = exclusive scan of it
+ *   (the row of p in every `[visible]`-gathered tensor), *count (device int32) = number visible. visible == NULL input to
+ *   points/points_backward means "all rows, rank = identity" (plain getters).
+ * points: rows j = rank[p] of means3D = xyz_qa(xyz), opacities = fq(sigmoid(opacity)), scale_factors =
+ *   exp(fq(scaling_factor)), sh_indices / g_indices copies (the five boolean-mask gathers of render()).
+ * *_backward: straight-through fake-quant masks x activation derivatives, recomputed from the raw tensors and the
+ *   state snapshot `state` (the caller passes a copy taken at forward time); P-sized outputs are fully written
+ *   (zeros for invisible rows). */
+size_t c3dgs_qat_workspace_bytes(void);
+int c3dgs_qat_observe(const c3dgs_qat_params* q, void* workspace, void* stream);
+int c3dgs_qat_codebooks(const c3dgs_qat_params* q, float* scales_n, float* rotations, float* shs, void* stream);
+int c3dgs_qat_codebooks_backward(const c3dgs_qat_params* q, const float* dL_dscales_n, const float* dL_drotations,
+                                 const float* dL_dshs, float* dL_dscaling, float* dL_drotation, float* dL_dfeatures_dc,
+                                 float* dL_dfeatures_rest, void* stream);
+size_t c3dgs_qat_scan_bytes(int32_t P);
+int c3dgs_qat_visible(const c3dgs_qat_params* q, const float* viewmatrix, uint8_t* visible /*[P]*/, int32_t* rank /*[P]*/,
+                      int32_t* count /*device [1]*/, void* scan_workspace, void* stream);
+int c3dgs_qat_points(const c3dgs_qat_params* q, const uint8_t* visible, const int32_t* rank, const int64_t* sh_indices,
+                     const int64_t* g_indices, float* means3D /*[V,3]*/, float* opacities /*[V,1]*/,
+                     float* scale_factors /*[V,1]*/, int64_t* sh_indices_out /*[V]*/, int64_t* g_indices_out /*[V]*/,
+                     void* stream);
+int c3dgs_qat_points_backward(const c3dgs_qat_params* q, const uint8_t* visible, const int32_t* rank,
+                              const float* dL_dmeans3D /*[V,3]*/, const float* dL_dmeans2D /*[V,3]*/,
+                              const float* dL_dopacities /*[V,1]*/, const float* dL_dscale_factors /*[V,1]*/,
+                              float* dL_dxyz /*[P,3]*/, float* dL_dscreenspace /*[P,3]*/, float* dL_dopacity /*[P,1]*/,
+                              float* dL_dscaling_factor /*[P,1]*/, void* stream);
+/* One stand-alone FakeQuantize module on an arbitrary tensor (the mirror of calling the torch module): observe (if
+ * `observe`), then out = fake_quantize_per_tensor_affine(x) (copy when !enabled); backward: dx = g * mask. */
+int c3dgs_fake_quantize(int64_t n, const float* x, c3dgs_fq_state* state, int32_t observe, int32_t enabled,
+                        float averaging_constant, float* out, void* workspace, void* stream);
+int c3dgs_fake_quantize_backward(int64_t n, const float* x, const c3dgs_fq_state* state, int32_t enabled, const float* g,
+                                 float* dx, void* stream);
+
 /* ---- introspection (tests and profiling only) ---- */
 typedef struct c3dgs_geom_layout {   /* byte offsets into the geometry buffer for P Gaussians */
     size_t total_bytes;
