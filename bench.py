@@ -235,6 +235,14 @@ def main():
     except Exception as e:
         out["qat_loop"] = {"error": repr(e)}
 
+    # ---- the whole QAT view from the RAW parameters -- getters (activations + FakeQuantize observers +
+    # [visible] gathers) + raster + fused loss + backward -- through c3dgs_amd.model.GaussianModel.render (fused glue),
+    # next to the reference's composition of the same glue from torch ops / torch.ao modules around the same rasterizer
+    try:
+        out["qat_model"] = bench_qat_model(c3dgs_amd, _lib, dev, ix_cpu, intr, evd, W, H, args.steps, barrier, world)
+    except Exception as e:
+        out["qat_model"] = {"error": repr(e)}
+
     # ---- VQ (config 4 colour shape), sharded over the ranks with one all-reduce per Lloyd step
     if not args.no_vq:
         try:
@@ -253,6 +261,69 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_qat_model(c3dgs_amd, _lib, dev, ix_cpu, intr, evd, W, H, steps, barrier, world):
+    from c3dgs_amd import loss as lossm
+    from c3dgs_amd import model as gm
+    from tests import synth
+    raw = synth.raw_params(ix_cpu)
+    m = gm.GaussianModel(3, quantization=True, device=dev).set_tensors(**raw)
+
+    class Cam:
+        intrinsic, extrinsic_vector = intr.to(dev), evd
+    cam, pipe, bg = Cam(), gm.PipelineParams(), torch.zeros(3, device=dev)
+    gt = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+
+    def fused_step():
+        for p in m.parameters():
+            p.grad = None
+        lossm.l1_ssim_loss(m.render(cam, pipe, bg)["render"], gt, 0.2).backward()
+
+    # the reference's glue (scene/gaussian_model.py:213-267, 766-886): torch ops + torch.ao modules + boolean gathers
+    mods = {k: torch.ao.quantization.FakeQuantize(dtype=torch.qint8).to(dev) for k in gm.SLOTS}
+    leaves = {k: v.to(dev).clone().requires_grad_(v.is_floating_point()) for k, v in raw.items()}
+    rs = c3dgs_amd.GaussianRasterizationSettings(intrinsic=cam.intrinsic, extrinsic_vector=evd, bg=bg, scale_modifier=1.0,
+                                                 sh_degree=3, prefiltered=False, debug=False, clamp_color=True)
+    rast = c3dgs_amd.GaussianRasterizerIndexed(rs, optimize_camera=True)
+    nz = torch.nn.functional.normalize
+
+    def torch_glue_step():
+        for v in leaves.values():
+            v.grad = None
+        xyz = gm.FakeQuantizationHalf.apply(leaves["xyz"])
+        opacity = mods["opacity"](torch.sigmoid(leaves["opacity"]))
+        scales = mods["scaling"](nz(torch.relu(leaves["scaling"])))
+        rotations = nz(mods["rotation"](leaves["rotation"]))
+        sfac = torch.exp(mods["scaling_factor"](leaves["scaling_factor"]))
+        shs = torch.cat((mods["features_dc"](leaves["features_dc"]), mods["features_rest"](leaves["features_rest"])), dim=1)
+        screen = torch.zeros_like(xyz, requires_grad=True)
+        vis = rast.markVisible(xyz, extrinsic_vector=evd)
+        color, _ = rast(means3D=xyz[vis], means2D=screen[vis], shs=shs, sh_indices=leaves["feature_indices"][vis],
+                        g_indices=leaves["gaussian_indices"][vis], colors_precomp=None, opacities=opacity[vis], scales=scales,
+                        scale_factors=sfac[vis], rotations=rotations, cov3D_precomp=None, extrinsic_vector=evd)
+        lossm.l1_ssim_loss(color, gt, 0.2).backward()
+
+    res = {"metric": "views/s of a whole QAT view from raw parameters (getters + raster + L1/SSIM loss + backward)"}
+    for name, fn in (("fused_glue", fused_step), ("torch_glue", torch_glue_step)):
+        for _ in range(4):
+            fn()
+        barrier()
+        if name == "fused_glue":
+            _lib.profile_enable(True)
+            _lib.profile_read()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        res[name] = {"views_per_s": world * steps / el, "ms_per_view": 1e3 * el / steps}
+        if name == "fused_glue":
+            st = _lib.profile_read()
+            _lib.profile_enable(False)
+            res["glue_stages_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in st.items() if k.startswith("qat_")}
+    res["glue_only_ms"] = {"fused": round(sum(res["glue_stages_ms"].values()), 4)}
+    return res
 
 
 def bench_vq(c3dgs_amd, _lib, dev, rank, world, steps):

@@ -52,6 +52,15 @@ class ImageLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("total_bytes", "final_T", "n_contrib", "ranges", "tile_used")]
 
 
+class QatParams(C.Structure):
+    _fields_ = [("P", C.c_int32), ("GS", C.c_int32), ("SHS", C.c_int32), ("M", C.c_int32),
+                ("xyz", C.c_void_p), ("opacity", C.c_void_p), ("scaling_factor", C.c_void_p), ("scaling", C.c_void_p),
+                ("rotation", C.c_void_p), ("features_dc", C.c_void_p), ("features_rest", C.c_void_p), ("state", C.c_void_p),
+                ("observer_enabled", C.c_int32 * 6), ("fake_quant_enabled", C.c_int32 * 6),
+                ("half_xyz", C.c_int32), ("averaging_constant", C.c_float)]
+
+
+_vp = C.c_void_p
 # name -> (restype, argtypes); every symbol include/c3dgs_hip.h declares
 PROTOTYPES = {
     "c3dgs_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -77,6 +86,16 @@ PROTOTYPES = {
                                         C.c_void_p]),
     "c3dgs_l1_ssim_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "c3dgs_qat_workspace_bytes": (C.c_size_t, []),
+    "c3dgs_qat_scan_bytes": (C.c_size_t, [C.c_int32]),
+    "c3dgs_qat_observe": (C.c_int, [C.POINTER(QatParams), _vp, _vp]),
+    "c3dgs_qat_codebooks": (C.c_int, [C.POINTER(QatParams), _vp, _vp, _vp, _vp]),
+    "c3dgs_qat_codebooks_backward": (C.c_int, [C.POINTER(QatParams)] + [_vp] * 8),
+    "c3dgs_qat_visible": (C.c_int, [C.POINTER(QatParams), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "c3dgs_qat_points": (C.c_int, [C.POINTER(QatParams)] + [_vp] * 10),
+    "c3dgs_qat_points_backward": (C.c_int, [C.POINTER(QatParams)] + [_vp] * 11),
+    "c3dgs_fake_quantize": (C.c_int, [C.c_int64, _vp, _vp, C.c_int32, C.c_int32, C.c_float, _vp, _vp, _vp]),
+    "c3dgs_fake_quantize_backward": (C.c_int, [C.c_int64, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "c3dgs_get_geom_layout": (C.c_int, [C.c_int32, C.POINTER(GeomLayout)]),
     "c3dgs_get_binning_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(BinningLayout)]),
     "c3dgs_get_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(ImageLayout)]),
@@ -122,6 +141,6 @@ def profile_enable(on=True):
 
 def profile_read():
     """-> {stage: (total_ms, count)} since the last read (synchronises the recorded events)."""
-    arr = (StageTime * 32)()
-    n = lib().c3dgs_profile_read(arr, 32)
+    arr = (StageTime * 48)()
+    n = lib().c3dgs_profile_read(arr, 48)
     return {arr[i].name.decode(): (float(arr[i].total_ms), int(arr[i].count)) for i in range(n)}

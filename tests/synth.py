@@ -64,3 +64,15 @@ def index_scene(sc, seed=99, shs_extra=4096, gs_extra=4096, sh_frac=0.1, g_frac=
 def grad_image(W, H, seed=4321):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(3, H, W, generator=g).float()
+
+
+def raw_params(ix):
+    """Learnable (pre-activation) tensors of an indexed scene, as scene/gaussian_model.py stores them: _opacity =
+    logit(opacity), _scaling_factor = log(scale factor), _scaling / _rotation codebooks, _features_dc / _features_rest
+    halves of the SH codebook. Feeding them through the getters reproduces `ix` up to fake-quantisation."""
+    op = ix["opacities"].clamp(1e-6, 1 - 1e-6)
+    return dict(xyz=ix["means3D"].clone(), opacity=torch.log(op / (1 - op)).float(),
+                scaling_factor=torch.log(ix["scale_factors"]).float(), scaling=ix["scales"].clone(),
+                rotation=ix["rotations"].clone(), features_dc=ix["shs"][:, :1].contiguous(),
+                features_rest=ix["shs"][:, 1:].contiguous(), feature_indices=ix["sh_indices"],
+                gaussian_indices=ix["g_indices"])
