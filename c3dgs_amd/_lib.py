@@ -82,6 +82,7 @@ PROTOTYPES = {
                                  C.c_int32, C.c_void_p]),
     "c3dgs_morton_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "c3dgs_morton_order": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c3dgs_extract_rot_scale": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "c3dgs_l1_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
     "c3dgs_l1_ssim_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -94,6 +95,7 @@ PROTOTYPES = {
     "c3dgs_qat_visible": (C.c_int, [C.POINTER(QatParams), _vp, _vp, _vp, _vp, _vp, _vp]),
     "c3dgs_qat_points": (C.c_int, [C.POINTER(QatParams)] + [_vp] * 10),
     "c3dgs_qat_points_backward": (C.c_int, [C.POINTER(QatParams)] + [_vp] * 11),
+    "c3dgs_qat_quantize": (C.c_int, [C.POINTER(QatParams), C.c_int32] + [_vp] * 7),
     "c3dgs_fake_quantize": (C.c_int, [C.c_int64, _vp, _vp, C.c_int32, C.c_int32, C.c_float, _vp, _vp, _vp]),
     "c3dgs_fake_quantize_backward": (C.c_int, [C.c_int64, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "c3dgs_get_geom_layout": (C.c_int, [C.c_int32, C.POINTER(GeomLayout)]),

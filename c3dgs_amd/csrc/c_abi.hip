@@ -362,6 +362,16 @@ int c3dgs_morton_order(int32_t P, const float* xyz, int64_t* codes, int64_t* ord
     return C3DGS_OK;
 }
 
+int c3dgs_extract_rot_scale(int32_t n, const float* cov6, float* rot, float* scale, void* stream)
+{
+    if (n < 0) return fail(C3DGS_E_INVALID, "extract_rot_scale: n must be >= 0");
+    if (n == 0) return C3DGS_OK;
+    if (!cov6 || !rot || !scale || (reinterpret_cast<uintptr_t>(rot) & 15)) return fail(C3DGS_E_INVALID, "extract_rot_scale: bad arguments");
+    launch_extract_rot_scale(n, cov6, rot, scale, (hipStream_t)stream);
+    C3DGS_STAGE("extract_rot_scale", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
 int c3dgs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, float* dmaps, double* sums,
                           void* stream)
 {
@@ -486,6 +496,16 @@ int c3dgs_qat_points_backward(const c3dgs_qat_params* q, const uint8_t* visible,
                                    dL_dscreenspace, dL_dopacity, dL_dscaling_factor, (hipStream_t)stream);
     }
     C3DGS_STAGE("qat_points_backward", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_qat_quantize(const c3dgs_qat_params* q, int32_t scaling_is_exp, int8_t* opacity, int8_t* scaling, int8_t* scaling_factor,
+                       int8_t* rotation, int8_t* features_dc, int8_t* features_rest, void* stream)
+{
+    if (int rc = qat_validate(q, "qat_quantize")) return rc;
+    if (rotation && (reinterpret_cast<uintptr_t>(rotation) & 3)) return fail(C3DGS_E_INVALID, "qat_quantize: rotation output must be 4-byte aligned");
+    launch_qat_quantize(*q, scaling_is_exp, opacity, scaling, scaling_factor, rotation, features_dc, features_rest, (hipStream_t)stream);
+    C3DGS_STAGE("qat_quantize", 0, (hipStream_t)stream);
     return C3DGS_OK;
 }
 

@@ -168,6 +168,7 @@ void launch_vq_apply(int K, int D, const float* S, float* codebook, float* entry
 // encode.hip
 size_t morton_workspace_bytes(int P);
 int run_morton_order(int P, const float* xyz, int64_t* codes_out, int64_t* order_out, void* workspace, hipStream_t s);
+void launch_extract_rot_scale(int n, const float* cov6, float* rot, float* scale, hipStream_t s);
 // loss.hip
 void launch_l1_ssim_forward(int C, int H, int W, const float* img, const float* gt, float* Dmu, float* Ds1, float* Ds12,
                             double* sums, hipStream_t s);
@@ -190,6 +191,8 @@ void launch_qat_points(const c3dgs_qat_params& q, const uint8_t* visible, const 
 void launch_qat_points_backward(const c3dgs_qat_params& q, const uint8_t* visible, const int32_t* rank, const float* g_m3,
                                 const float* g_m2, const float* g_op, const float* g_sf, float* d_xyz, float* d_screen,
                                 float* d_op, float* d_sf, hipStream_t s);
+void launch_qat_quantize(const c3dgs_qat_params& q, int scaling_exp, int8_t* opacity, int8_t* scaling, int8_t* scaling_factor,
+                         int8_t* rotation, int8_t* features_dc, int8_t* features_rest, hipStream_t s);
 void launch_fake_quantize(long long n, const float* x, c3dgs_fq_state* state, int observe, int enabled, float c, float* out,
                           void* workspace, hipStream_t s);
 void launch_fake_quantize_backward(long long n, const float* x, const c3dgs_fq_state* state, int enabled, const float* g,

@@ -125,4 +125,97 @@ int run_morton_order(int P, const float* xyz, int64_t* codes_out, int64_t* order
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// extract_rot_scale(to_full_cov(cov6))  (utils/splats.py:7-35, used by compress_covariance, compression/vq.py:186):
+// eigendecomposition of the symmetric 3x3 covariance of every codebook entry -> (unit quaternion, sqrt eigenvalues).
+// The reference calls torch.linalg.eigh (a batched LAPACK / solver call, ascending eigenvalues) and then
+// matrix_to_quaternion(R * det(R)); here ONE thread per matrix runs a cyclic Jacobi iteration in fp64 (converges to
+// fp64 round-off in <= 6 sweeps for 3x3, so the fp32 results carry no iteration error), sorts ascending, fixes the
+// handedness and converts with the same best-conditioned-candidate rule. Eigenvector SIGNS are not determined by the
+// problem (LAPACK's choice is arbitrary as well): parity is on the eigenvalues and on R diag(s^2) R^T.
+__device__ __forceinline__ void jacobi_rotate(double a[3][3], double v[3][3], int p, int q)
+{
+    if (a[p][q] == 0.0) return;
+    const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+    const int r = 3 - p - q;
+    const double apr = a[p][r], aqr = a[q][r];
+    a[p][p] -= t * a[p][q];
+    a[q][q] += t * a[p][q];
+    a[p][q] = a[q][p] = 0.0;
+    a[p][r] = a[r][p] = c * apr - sn * aqr;
+    a[q][r] = a[r][q] = sn * apr + c * aqr;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double vp = v[k][p], vq = v[k][q];
+        v[k][p] = c * vp - sn * vq;
+        v[k][q] = sn * vp + c * vq;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+extract_rot_scale_kernel(int n, const float* __restrict__ cov6, float* __restrict__ rot, float* __restrict__ scale)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* cv = cov6 + 6 * (size_t)i;
+    const float e = 1e-8f;                                       // cov + eye(3) * 1e-8, in fp32 as torch evaluates it
+    double a[3][3] = { { (double)(cv[0] + e), (double)cv[1], (double)cv[2] },
+                       { (double)cv[1], (double)(cv[3] + e), (double)cv[4] },
+                       { (double)cv[2], (double)cv[4], (double)(cv[5] + e) } };
+    double v[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+    for (int sweep = 0; sweep < 10; sweep++) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        const double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
+        if (off <= 1e-300 || off <= 1e-22 * diag) break;
+        jacobi_rotate(a, v, 0, 1);
+        jacobi_rotate(a, v, 0, 2);
+        jacobi_rotate(a, v, 1, 2);
+    }
+    // ascending eigenvalues (torch.linalg.eigh order); columns of v follow
+    int o0 = 0, o1 = 1, o2 = 2;
+    double w0 = a[0][0], w1 = a[1][1], w2 = a[2][2];
+    if (w0 > w1) { double t = w0; w0 = w1; w1 = t; int k = o0; o0 = o1; o1 = k; }
+    if (w1 > w2) { double t = w1; w1 = w2; w2 = t; int k = o1; o1 = o2; o2 = k; }
+    if (w0 > w1) { double t = w0; w0 = w1; w1 = t; int k = o0; o0 = o1; o1 = k; }
+    const float S[3] = { (float)w0, (float)w1, (float)w2 };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float sq = sqrtf(S[k]);
+        scale[3 * (size_t)i + k] = (sq != sq) ? 1e-6f : sq;      // S.sqrt().nan_to_num(nan=1e-6)
+    }
+    float m[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { m[r][0] = (float)v[r][o0]; m[r][1] = (float)v[r][o1]; m[r][2] = (float)v[r][o2]; }
+    const float det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                      m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) m[r][c] *= det;              // R * R.det(): determinant +1
+    // matrix_to_quaternion (utils/splats.py:43-105): best-conditioned of the four candidates
+    const float qa[4] = { 1.f + m[0][0] + m[1][1] + m[2][2], 1.f + m[0][0] - m[1][1] - m[2][2],
+                          1.f - m[0][0] + m[1][1] - m[2][2], 1.f - m[0][0] - m[1][1] + m[2][2] };
+    float q_abs[4];
+    int best = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { q_abs[k] = qa[k] > 0.f ? sqrtf(qa[k]) : 0.f; if (q_abs[k] > q_abs[best]) best = k; }
+    float c4[4];
+    if (best == 0) { c4[0] = q_abs[0] * q_abs[0]; c4[1] = m[2][1] - m[1][2]; c4[2] = m[0][2] - m[2][0]; c4[3] = m[1][0] - m[0][1]; }
+    else if (best == 1) { c4[0] = m[2][1] - m[1][2]; c4[1] = q_abs[1] * q_abs[1]; c4[2] = m[1][0] + m[0][1]; c4[3] = m[0][2] + m[2][0]; }
+    else if (best == 2) { c4[0] = m[0][2] - m[2][0]; c4[1] = m[1][0] + m[0][1]; c4[2] = q_abs[2] * q_abs[2]; c4[3] = m[1][2] + m[2][1]; }
+    else { c4[0] = m[1][0] - m[0][1]; c4[1] = m[2][0] + m[0][2]; c4[2] = m[2][1] + m[1][2]; c4[3] = q_abs[3] * q_abs[3]; }
+    const float den = 2.0f * fmaxf(q_abs[best], 0.1f);
+    float qv[4] = { c4[0] / den, c4[1] / den, c4[2] / den, c4[3] / den };
+    const float nrm = fmaxf(sqrtf(qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2] + qv[3] * qv[3]), 1e-12f);   // F.normalize
+    reinterpret_cast<float4*>(rot)[i] = make_float4(qv[0] / nrm, qv[1] / nrm, qv[2] / nrm, qv[3] / nrm);
+}
+
+void launch_extract_rot_scale(int n, const float* cov6, float* rot, float* scale, hipStream_t s)
+{
+    if (n <= 0) return;
+    extract_rot_scale_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, cov6, rot, scale);
+}
+
 } // namespace c3dgs

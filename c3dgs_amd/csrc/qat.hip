@@ -457,6 +457,83 @@ void launch_qat_points_backward(const c3dgs_qat_params& q, const uint8_t* visibl
     qat_points_backward_kernel<<<(q.P + 255) / 256, 256, 0, s>>>(q, visible, rank, g_m3, g_m2, g_op, g_sf, d_xyz, d_screen, d_op, d_sf);
 }
 
+// ------------------------------------------------------------------------------------------- int8 payload (save_npz)
+// torch.quantize_per_tensor(...).int_repr() of the activated tensors (scene/gaussian_model.py:525-617). The device
+// kernel of torch evaluates nearbyint(double(x) / double(scale)) + zero_point (checked against torch on the MI355X box:
+// bit-identical codes; the fp32 multiply-by-reciprocal of torch's CPU path differs at rounding ties), so does this one.
+enum { QACT_IDENT = 0, QACT_SIGMOID = 1, QACT_NORMRELU3 = 2, QACT_NORM4 = 3, QACT_EXP = 4 };
+struct QuantJob { const float* x; int8_t* out; long long units; int act; int slot; int first_block; int nblocks; };
+struct QuantJobs { QuantJob j[C3DGS_FQ_COUNT]; int n; };
+
+__device__ __forceinline__ int8_t quant_code(float v, double scale, int zp)
+{
+    const double q = nearbyint((double)v / scale) + (double)zp;
+    return (int8_t)fmin(127.0, fmax(-128.0, q));
+}
+
+__global__ void __launch_bounds__(256)
+qat_quantize_kernel(const QuantJobs jobs, const c3dgs_fq_state* __restrict__ state)
+{
+    int t = 0;
+#pragma unroll
+    for (int k = 1; k < C3DGS_FQ_COUNT; k++)
+        if (k < jobs.n && (int)blockIdx.x >= jobs.j[k].first_block) t = k;
+    const QuantJob job = jobs.j[t];
+    const double scale = (double)state[job.slot].scale;
+    const int zp = state[job.slot].zero_point;
+    const long long stride = (long long)job.nblocks * 256, i0 = (long long)(blockIdx.x - job.first_block) * 256 + threadIdx.x;
+    if (job.act == QACT_NORMRELU3) {
+        for (long long r = i0; r < job.units; r += stride) {
+            const float x[3] = { job.x[3 * r], job.x[3 * r + 1], job.x[3 * r + 2] };
+            float u[3], v[3], n;
+            normrelu3(x, u, v, n);
+#pragma unroll
+            for (int k = 0; k < 3; k++) job.out[3 * r + k] = quant_code(v[k], scale, zp);
+        }
+    } else if (job.act == QACT_NORM4) {      // rotation_activation(_rotation) = normalize(q), gaussian_model.py:606
+        for (long long r = i0; r < job.units; r += stride) {
+            const float4 w = reinterpret_cast<const float4*>(job.x)[r];
+            const float d = fmaxf(sqrtf(w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w), NORM_EPS);
+            char4 o;
+            o.x = quant_code(w.x / d, scale, zp); o.y = quant_code(w.y / d, scale, zp);
+            o.z = quant_code(w.z / d, scale, zp); o.w = quant_code(w.w / d, scale, zp);
+            reinterpret_cast<char4*>(job.out)[r] = o;
+        }
+    } else {
+        for (long long i = i0; i < job.units; i += stride) {
+            float v = job.x[i];
+            if (job.act == QACT_SIGMOID) v = sigmoid_f(v);
+            else if (job.act == QACT_EXP) v = expf(v);
+            job.out[i] = quant_code(v, scale, zp);
+        }
+    }
+}
+
+void launch_qat_quantize(const c3dgs_qat_params& q, int scaling_exp, int8_t* opacity, int8_t* scaling, int8_t* scaling_factor,
+                         int8_t* rotation, int8_t* features_dc, int8_t* features_rest, hipStream_t s)
+{
+    QuantJobs J; J.n = 0;
+    int nb = 0;
+    auto add = [&](const float* x, int8_t* out, long long units, int act, int slot) {
+        if (!x || !out || units <= 0) return;
+        QuantJob& j = J.j[J.n++];
+        j.x = x; j.out = out; j.units = units; j.act = act; j.slot = slot; j.first_block = nb;
+        const long long want = (units + 1023) / 1024;
+        j.nblocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+        nb += j.nblocks;
+    };
+    const long long P = q.P, GS = q.GS, SHS = q.SHS;
+    add(q.opacity, opacity, P, QACT_SIGMOID, C3DGS_FQ_OPACITY);
+    if (scaling_exp) add(q.scaling, scaling, GS * 3, QACT_EXP, C3DGS_FQ_SCALING);
+    else add(q.scaling, scaling, GS, QACT_NORMRELU3, C3DGS_FQ_SCALING);
+    add(q.scaling_factor, scaling_factor, P, QACT_IDENT, C3DGS_FQ_SCALING_FACTOR);
+    add(q.rotation, rotation, GS, QACT_NORM4, C3DGS_FQ_ROTATION);
+    add(q.features_dc, features_dc, SHS * 3, QACT_IDENT, C3DGS_FQ_FEATURES_DC);
+    add(q.features_rest, features_rest, SHS * 3 * (q.M - 1), QACT_IDENT, C3DGS_FQ_FEATURES_REST);
+    if (J.n == 0) return;
+    qat_quantize_kernel<<<nb, 256, 0, s>>>(J, q.state);
+}
+
 // ------------------------------------------------------------------------------------------- stand-alone module
 __global__ void __launch_bounds__(256)
 fq_elementwise_kernel(long long n, const float* __restrict__ x, const c3dgs_fq_state* __restrict__ state, int enabled,

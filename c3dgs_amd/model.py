@@ -430,6 +430,126 @@ class GaussianModel:
     def get_normalized_covariance(self, scaling_modifier=1, strip_sym=True):
         return _covariance(self.get_scaling_normalized, scaling_modifier, self.get_rotation, strip_sym)
 
+    # ---- on-disk payload (gaussian_model.py:505-623 save_npz, :625-720 load_npz, :997-1023 _sort_morton)
+    def _sort_morton(self):
+        from . import encode
+        with torch.no_grad():
+            order = encode.morton_order(self._xyz.detach())
+            take = lambda t: None if t is None else t.detach()[order].contiguous().requires_grad_(t.requires_grad)
+            self._xyz, self._opacity, self._scaling_factor = take(self._xyz), take(self._opacity), take(self._scaling_factor)
+            if self.is_color_indexed:
+                self._feature_indices = self._feature_indices[order].contiguous()
+            else:
+                self._features_rest, self._features_dc = take(self._features_rest), take(self._features_dc)
+            if self.is_gaussian_indexed:
+                self._gaussian_indices = self._gaussian_indices[order].contiguous()
+            else:
+                self._scaling, self._rotation = take(self._scaling), take(self._rotation)
+
+    def quantized_payload(self):
+        """int8 codes of every fake-quantised tensor with the modules' current scale / zero_point, as
+        torch.quantize_per_tensor(...).int_repr() gives them in save_npz: ONE launch for all six tensors."""
+        dev = self.device
+        i8 = lambda t: None if t is None else torch.empty(t.shape, dtype=torch.int8, device=dev)
+        raw = dict(opacity=self._opacity, scaling=self._scaling, scaling_factor=self._scaling_factor, rotation=self._rotation,
+                   fdc=self._features_dc, frest=self._features_rest)
+        raw = {k: (None if v is None else v.detach().contiguous()) for k, v in raw.items()}
+        out = {k: i8(v) for k, v in raw.items()}
+        q = _qat_params(self, self._fq_state, **raw)
+        _lib.check(_lib.lib().c3dgs_qat_quantize(C.byref(q), int(not self.use_factor_scaling), _ptr(out["opacity"]),
+                                                 _ptr(out["scaling"]), _ptr(out["scaling_factor"]), _ptr(out["rotation"]),
+                                                 _ptr(out["fdc"]), _ptr(out["frest"]), _stream(dev)))
+        return out
+
+    def save_npz(self, path, compress=True, half_precision=False, sort_morton=False):
+        """Same keys, dtypes and shapes as the reference writes, so its load_npz / the web viewer read the file."""
+        import os
+        import numpy as np
+        with torch.no_grad():
+            if sort_morton:
+                self._sort_morton()
+            if isinstance(path, str):
+                os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            dtype = torch.half if half_precision else torch.float32
+            d = {"quantization": self.quantization}
+            host = lambda t: t.detach().cpu().numpy()
+            if self.quantization:
+                codes = self.quantized_payload()
+                d["xyz"] = host(self._xyz.detach().half())
+                for key, name, slot in (("features_dc", "fdc", "features_dc"), ("features_rest", "frest", "features_rest"),
+                                        ("opacity", "opacity", "opacity"), ("scaling", "scaling", "scaling"),
+                                        ("scaling_factor", "scaling_factor", "scaling_factor"),
+                                        ("rotation", "rotation", "rotation")):
+                    if codes[name] is None:
+                        continue
+                    mod = self._modules_qa[slot]
+                    d[key] = host(codes[name])
+                    d[key + "_scale"] = host(mod.scale)
+                    d[key + "_zero_point"] = host(mod.zero_point)
+            else:
+                d["xyz"] = host(self._xyz)
+                d["features_dc"], d["features_rest"] = host(self._features_dc), host(self._features_rest)
+                d["opacity"] = host(self._opacity.detach().to(dtype))
+                d["scaling"] = host(self._scaling.detach().to(dtype))
+                if self._scaling_factor is not None:
+                    d["scaling_factor"] = host(self._scaling_factor.detach().to(dtype))
+                d["rotation"] = host(self._rotation.detach().to(dtype))
+            if self.is_color_indexed:
+                d["feature_indices"] = host(self._feature_indices.int())
+            if self.is_gaussian_indexed:
+                d["gaussian_indices"] = host(self._gaussian_indices.int())
+            # key order of the reference's file
+            order = ["quantization", "xyz", "features_dc", "features_dc_scale", "features_dc_zero_point", "features_rest",
+                     "features_rest_scale", "features_rest_zero_point", "opacity", "opacity_scale", "opacity_zero_point",
+                     "feature_indices", "gaussian_indices", "scaling", "scaling_scale", "scaling_zero_point",
+                     "scaling_factor", "scaling_factor_scale", "scaling_factor_zero_point", "rotation", "rotation_scale",
+                     "rotation_zero_point"]
+            (np.savez_compressed if compress else np.savez)(path, **{k: d[k] for k in order if k in d})
+
+    def load_npz(self, path, override_quantization=False):
+        import numpy as np
+        sd = np.load(path)                                      # plain arrays only (allow_pickle stays False)
+        quantization = bool(sd["quantization"])
+        if not override_quantization and self.quantization != quantization:
+            print("WARNING: model is not quantisation aware but loaded model is")
+        if override_quantization:
+            self.quantization = quantization
+        dev = self.device
+        par = lambda t: t.to(dev, torch.float32).contiguous().requires_grad_(True)
+
+        def dequant(key, slot):
+            qv = torch.from_numpy(sd[key]).int().to(dev)
+            scale = torch.from_numpy(sd[key + "_scale"]).to(dev)
+            zp = torch.from_numpy(sd[key + "_zero_point"]).to(dev)
+            val = (qv - zp) * scale
+            row = self._modules_qa[slot]._row
+            row[0], row[1], row[2] = val.min(), val.max(), scale.reshape(-1)[0]
+            row[3:4].view(torch.int32)[0] = zp.reshape(-1)[0].int()
+            return val
+
+        self._xyz = par(torch.from_numpy(sd["xyz"]).float())
+        if quantization:
+            self._features_rest = par(dequant("features_rest", "features_rest"))
+            self._features_dc = par(dequant("features_dc", "features_dc"))
+            op = dequant("opacity", "opacity")
+            self._opacity = par(torch.log(op / (1 - op)))       # inverse_sigmoid
+            sc = dequant("scaling", "scaling")
+            self._scaling = par(sc if self.use_factor_scaling else torch.log(sc))
+            self._scaling_factor = par(dequant("scaling_factor", "scaling_factor")) if "scaling_factor" in sd else None
+            self._rotation = par(dequant("rotation", "rotation"))
+        else:
+            self._features_dc, self._features_rest = par(torch.from_numpy(sd["features_dc"]).float()), \
+                par(torch.from_numpy(sd["features_rest"]).float())
+            self._opacity = par(torch.from_numpy(sd["opacity"]).float())
+            self._scaling_factor = par(torch.from_numpy(sd["scaling_factor"]).float()) if "scaling_factor" in sd else None
+            self._scaling = par(torch.from_numpy(sd["scaling"]).float())
+            self._rotation = par(torch.from_numpy(sd["rotation"]).float())
+        self._feature_indices = torch.from_numpy(sd["feature_indices"]).long().to(dev) if "feature_indices" in sd else None
+        self._gaussian_indices = torch.from_numpy(sd["gaussian_indices"]).long().to(dev) if "gaussian_indices" in sd else None
+        self.color_index_mode = ColorMode.ALL_INDEXED if self._feature_indices is not None else ColorMode.NOT_INDEXED
+        self.active_sh_degree = self.max_sh_degree
+        return self
+
     # ---- render (gaussian_model.py:766-886)
     def render(self, viewpoint_camera, pipe, bg_color, scaling_modifier=1.0, override_color=None, clamp_color=True,
                cov3d=None):

@@ -275,8 +275,8 @@ def compress_color(gaussians, color_importance: torch.Tensor, color_comp: Compre
 
 def compress_covariance(gaussians, gaussian_importance: torch.Tensor, gaussian_comp: CompressionSettings, silent: bool,
                         group=None, extract_rot_scale=None, to_full_cov=None):
-    """compression/vq.py:149-191. The eigendecomposition helpers (utils/splats.py:7-35) are host-model code
-    outside the hot path; pass them in (the reference's own functions work unchanged)."""
+    """compression/vq.py:149-191. The eigendecomposition helpers default to c3dgs_amd.encode's HIP versions of
+    utils/splats.py:7-35; the reference's own functions can still be passed in."""
     keep_mask_g = gaussian_importance > gaussian_comp.importance_include
     vq_mask_g = ~keep_mask_g
     if not silent:
@@ -293,7 +293,8 @@ def compress_covariance(gaussians, gaussian_importance: torch.Tensor, gaussian_c
         cov_vq_indices = torch.empty((0,), device=covariance.device, dtype=torch.long)
     compressed_cov, cov_indices = join_features(covariance, keep_mask_g, cov_codebook, cov_vq_indices)
     if extract_rot_scale is None or to_full_cov is None:
-        raise RuntimeError("compress_covariance needs extract_rot_scale and to_full_cov (reference utils/splats.py)")
+        from . import encode
+        extract_rot_scale, to_full_cov = encode.extract_rot_scale, encode.to_full_cov
     rot_vq, scale_vq = extract_rot_scale(to_full_cov(compressed_cov))
     gaussians.set_gaussian_indexed(rot_vq.to(compressed_cov.device), scale_vq.to(compressed_cov.device), cov_indices)
 

@@ -162,6 +162,11 @@ size_t c3dgs_morton_workspace_bytes(int32_t P);
 int c3dgs_morton_order(int32_t P, const float* xyz /*[P,3]*/, int64_t* codes /*[P]*/, int64_t* order /*[P]*/,
                        void* workspace, void* stream);
 
+/* ---- extract_rot_scale(to_full_cov(cov)) (utils/splats.py:7-35; compress_covariance, compression/vq.py:186):
+ * cov6[n,6] = upper triangle (xx,xy,xz,yy,yz,zz) -> rot[n,4] unit quaternion (r,x,y,z) of the eigenvector frame with
+ * determinant +1, scale[n,3] = sqrt of the ascending eigenvalues of cov + 1e-8 I (NaN -> 1e-6). */
+int c3dgs_extract_rot_scale(int32_t n, const float* cov6, float* rot, float* scale, void* stream);
+
 /* ---- QAT getters: activation + fake-quant + visibility gathers in front of every raster call -------------------
  * SURVEY.md 8(f) row N1; reference scene/gaussian_model.py:54-77 (activations), :109-118 (seven
  * torch.ao.quantization.FakeQuantize(dtype=qint8) modules = MovingAverageMinMaxObserver, per-tensor affine,
@@ -229,6 +234,13 @@ int c3dgs_qat_points_backward(const c3dgs_qat_params* q, const uint8_t* visible,
                               const float* dL_dopacities /*[V,1]*/, const float* dL_dscale_factors /*[V,1]*/,
                               float* dL_dxyz /*[P,3]*/, float* dL_dscreenspace /*[P,3]*/, float* dL_dopacity /*[P,1]*/,
                               float* dL_dscaling_factor /*[P,1]*/, void* stream);
+/* int8 payload of GaussianModel.save_npz (scene/gaussian_model.py:525-617): per tensor
+ * torch.quantize_per_tensor(activation(raw), scale, zero_point, qint8).int_repr() with the module's CURRENT state:
+ * opacity <- sigmoid, scaling <- normalize(relu) (or exp when scaling_is_exp), rotation <- normalize, the rest raw.
+ * NULL outputs (or NULL inputs in `q`) are skipped. */
+int c3dgs_qat_quantize(const c3dgs_qat_params* q, int32_t scaling_is_exp, int8_t* opacity /*[P,1]*/, int8_t* scaling /*[GS,3]*/,
+                       int8_t* scaling_factor /*[P,1]*/, int8_t* rotation /*[GS,4]*/, int8_t* features_dc /*[SHS,1,3]*/,
+                       int8_t* features_rest /*[SHS,M-1,3]*/, void* stream);
 /* One stand-alone FakeQuantize module on an arbitrary tensor (the mirror of calling the torch module): observe (if
  * `observe`), then out = fake_quantize_per_tensor_affine(x) (copy when !enabled); backward: dx = g * mask. */
 int c3dgs_fake_quantize(int64_t n, const float* x, c3dgs_fq_state* state, int32_t observe, int32_t enabled,

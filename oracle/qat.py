@@ -177,3 +177,16 @@ def visible_rows(xyz_q, viewmatrix):
     pz = (pz + m[10] * z).astype(np.float32)
     pz = (pz + m[14]).astype(np.float32)
     return ~(pz <= F32(0.01))
+
+
+def quantize_codes(st, x, device_rounding=True):
+    """torch.quantize_per_tensor(x, scale, zero_point, qint8).int_repr() (save_npz, scene/gaussian_model.py:525-617).
+    torch's device kernel rounds nearbyint(double(x) / double(scale)) (device_rounding=True; what the reference's GPU
+    save path produces, verified on the MI355X box); its CPU path rounds fp32 x * (1/scale) (device_rounding=False,
+    pinned bit-exact against CPU torch in tests/test_oracle_qat.py). The two differ only at rounding ties."""
+    x = np.asarray(x, np.float32)
+    if device_rounding:
+        q = np.rint(x.astype(np.float64) / np.float64(st.scale)) + st.zero_point
+    else:
+        q = np.rint(x * F32(F32(1.0) / st.scale)).astype(np.float64) + st.zero_point
+    return np.clip(q, QMIN, QMAX).astype(np.int8)

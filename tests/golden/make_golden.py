@@ -11,6 +11,8 @@ What it pins; the fixtures hold data only (inputs + exp
   cov3d.npz      utils/general_utils.py:build_covariance_from_scaling_rotation -> K2's cov3D
   loss.npz       utils/loss_utils.py: (1-l)*l1_loss + l*(1-ssim) and its autograd gradient (finetune.py:48)
   morton.npz     mortonEncode/splitBy3 (scene/gaussian_model.py:1417-1432) on _sort_morton's quantisation (:999-1003)
+  splats.npz     utils/splats.py: extract_rot_scale(to_full_cov(cov6)) and build_covariance of its result (pure torch,
+                 importable): the eigendecomposition step of compress_covariance (compression/vq.py:186)
   camgrad.npz    the closed-form grad_params block of _RasterizeGaussiansIndexedCamera.backward
                  (diff_gaussian_rasterization_no_camera/__init__.py:674-844), executed on CPU tensors
 """
@@ -159,6 +161,28 @@ def gen_morton():
     print("morton.npz")
 
 
+def gen_splats():
+    from utils.splats import build_covariance, extract_rot_scale, to_full_cov
+    g = torch.Generator().manual_seed(12)
+    n = 600
+    s = torch.exp(torch.randn(n, 3, generator=g) * 0.8)
+    s = s / s.norm(dim=1, keepdim=True)                                   # normalised scaling, as get_normalized_covariance
+    s[:40, 1] = s[:40, 0]                                                 # repeated eigenvalue
+    s[40:60, 2] = 1e-5                                                    # nearly flat
+    q = torch.randn(n, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    from utils.general_utils import build_covariance_from_scaling_rotation
+    cov6 = build_covariance_from_scaling_rotation(s, 1.0, q).float()
+    cov6[60:80] = (cov6[60:80] + cov6[80:100]) * 0.5                      # codebook entries are weighted MEANS of covariances
+    cov6[100] = 0.0                                                       # degenerate: all-zero entry
+    cov6[101] = torch.tensor([1.0, 0, 0, 1.0, 0, 1.0])                    # identity
+    rot, scaling = extract_rot_scale(to_full_cov(cov6))
+    rebuilt = build_covariance(rot, scaling)
+    np.savez_compressed(os.path.join(OUT, "splats.npz"), cov6=cov6.numpy(), rot=rot.numpy(), scaling=scaling.numpy(),
+                        rebuilt=rebuilt.numpy())
+    print("splats.npz")
+
+
 def gen_loss():
     """finetune.py:48 loss and its autograd gradient, utils/loss_utils.py (pure torch, importable)."""
     from utils.loss_utils import l1_loss, ssim
@@ -188,3 +212,4 @@ if __name__ == "__main__":
     gen_camgrad()
     gen_loss()
     gen_morton()
+    gen_splats()

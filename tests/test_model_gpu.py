@@ -248,3 +248,60 @@ def test_cpu_tensor_is_rejected_loudly():
     from c3dgs_amd.model import FakeQuantize
     with pytest.raises(RuntimeError, match="no CPU path"):
         FakeQuantize(device=DEV)(torch.randn(10))
+
+
+def test_save_npz_codes_equal_device_torch_quantize_and_file_round_trips(tmp_path):
+    """Row N4 container: the int8 payload must equal torch.quantize_per_tensor(...).int_repr() run on this device with
+    the same scale / zero_point (that is what the reference's save_npz stores), the file must carry the reference's
+    keys / dtypes, and load_npz must bring back a model that renders the same image."""
+    from c3dgs_amd.model import GaussianModel, PipelineParams
+    W, H = 320, 200
+    raw = _raw(21, P=12000, W=W, H=H)
+    m = _model(raw)
+    intr, ev = synth.camera(W, H, 300.0)
+    cam, bg = _Cam(intr, ev), torch.zeros(3, device=DEV)
+    img0 = m.render(cam, PipelineParams(), bg)["render"].detach()      # populates every observer
+    path = str(tmp_path / "scene.npz")
+    m.save_npz(path, sort_morton=False)
+    sd = np.load(path)
+    nz = torch.nn.functional.normalize
+    acts = {"opacity": torch.sigmoid(m._opacity), "scaling": nz(torch.relu(m._scaling)), "scaling_factor": m._scaling_factor,
+            "rotation": nz(m._rotation), "features_dc": m._features_dc, "features_rest": m._features_rest}
+    g = qat.Getters(True)
+    for k, t in acts.items():
+        mod = m._modules_qa[k]
+        want = torch.quantize_per_tensor(t.detach(), mod.scale, mod.zero_point, torch.qint8).int_repr().cpu().numpy()
+        got = sd[k]
+        assert got.dtype == np.int8 and got.shape == want.shape, k
+        exact = k in ("scaling_factor", "features_dc", "features_rest")
+        if exact:
+            assert np.array_equal(got, want), k
+        else:                                                   # activation ulps can move a code at a tie
+            d = got.astype(np.int32) - want
+            assert (d != 0).mean() < 1e-3 and np.abs(d).max() <= 1, (k, (d != 0).mean())
+        st = qat.FqState(); st.scale = np.float32(float(mod.scale)); st.zero_point = int(mod.zero_point)
+        if exact:
+            assert np.array_equal(got, qat.quantize_codes(st, t.detach().cpu().numpy())), k
+        assert sd[k + "_scale"].dtype == np.float32 and sd[k + "_scale"].shape == (1,)
+        assert sd[k + "_zero_point"].dtype == np.int32 and sd[k + "_zero_point"].shape == (1,)
+    assert sd["xyz"].dtype == np.float16 and np.array_equal(sd["xyz"], raw["xyz"].half().numpy())
+    assert sd["feature_indices"].dtype == np.int32 and sd["gaussian_indices"].dtype == np.int32
+    assert bool(sd["quantization"]) is True
+    # round trip
+    m2 = GaussianModel(3, quantization=True, device=DEV).load_npz(path)
+    for mod in m2._modules_qa.values():
+        mod.disable_observer()                                  # render with the loaded scale / zero_point
+    for mod in m._modules_qa.values():
+        mod.disable_observer()
+    img1 = m.render(cam, PipelineParams(), bg)["render"].detach()
+    img2 = m2.render(cam, PipelineParams(), bg)["render"].detach()
+    mse = float(((img1 - img2) ** 2).mean())
+    # the stored scaling codes are re-normalised on load (normalize(relu(dequant))), as in the reference: close, not equal
+    assert mse < 1e-4, mse
+    assert float(((img0 - img1) ** 2).mean()) < 1e-9
+    # morton-sorted save: same set of points, permuted
+    m.save_npz(str(tmp_path / "sorted.npz"), sort_morton=True)
+    sd2 = np.load(str(tmp_path / "sorted.npz"))
+    assert sorted(map(tuple, sd2["xyz"].astype(np.float32))) == sorted(map(tuple, sd["xyz"].astype(np.float32)))
+    from oracle import oracle as orc
+    assert np.array_equal(sd2["xyz"], raw["xyz"].numpy()[orc.morton_order(raw["xyz"].numpy())].astype(np.float16))

@@ -77,3 +77,18 @@ def test_vq_update_empty_clusters_decay_toward_zero(orc):
     np.testing.assert_allclose(cb[1], 0.8 * 9, rtol=1e-6)
     np.testing.assert_allclose(cb[0], 0.8 * 0.5 + 0.2 * (8.0 / (16 + 1e-5)), rtol=1e-6)
     np.testing.assert_allclose(ent, [0.2 * 16, 0.0], rtol=1e-6)
+
+
+def test_splats_oracle_matches_reference_extract_rot_scale_golden():
+    """oracle/splats.py vs the reference's utils/splats.py outputs (tests/golden/splats.npz)."""
+    import os
+    import numpy as np
+    from oracle import splats
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "splats.npz"))
+    rot, scaling = splats.extract_rot_scale(splats.to_full_cov(g["cov6"]))
+    lam_max = (g["scaling"] ** 2).max(1, keepdims=True)
+    np.testing.assert_allclose(scaling ** 2, g["scaling"] ** 2, rtol=0, atol=float(3e-6 * lam_max.max()))
+    np.testing.assert_allclose(np.linalg.norm(rot, axis=1), 1.0, atol=1e-6)
+    rebuilt = splats.build_covariance(rot, scaling)
+    np.testing.assert_allclose(rebuilt, g["rebuilt"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(rebuilt, splats.to_full_cov(g["cov6"]), rtol=0, atol=5e-6)

@@ -128,3 +128,16 @@ def test_visible_rows_matches_raster_oracle_mark_visible():
                      np.array([0.05, -0.02, 0.03, 0.99, 0.1, -0.2, 0.4], np.float32))
     vis = orc.mark_visible(qat.half_round(xyz), cam["viewmatrix"], cam["projmatrix"])
     assert np.array_equal(qat.visible_rows(qat.half_round(xyz), cam["viewmatrix"]), vis.astype(bool))
+
+
+def test_quantize_codes_cpu_rounding_is_bit_exact_with_torch_and_device_rounding_differs_only_at_ties():
+    fq = torch.ao.quantization.FakeQuantize(dtype=torch.qint8)
+    st = qat.FqState()
+    x = torch.randn(400000, generator=torch.Generator().manual_seed(2)) * 2
+    fq(x)
+    qat.observe(st, x.numpy())
+    want = torch.quantize_per_tensor(x, fq.scale, fq.zero_point, fq.dtype).int_repr().numpy()
+    assert np.array_equal(qat.quantize_codes(st, x.numpy(), device_rounding=False), want)
+    dev = qat.quantize_codes(st, x.numpy(), device_rounding=True)
+    diff = dev.astype(np.int32) - want
+    assert (diff != 0).mean() < 1e-4 and np.abs(diff).max() <= 1
