@@ -309,8 +309,12 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     const int last_contributor = inside ? (int)n_contrib[pix] : 0;
     float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
     if (inside) { dpx0 = dL_dpixels[pix]; dpx1 = dL_dpixels[HW + pix]; dpx2 = dL_dpixels[2 * HW + pix]; }
-    const float bg_dot = bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    // Running "what lies behind" term. The reference keeps the blended colour behind the current Gaussian as a
+    // 3-channel recurrence (accum_rec / last_alpha / last_color, backward.cu:505-521) and adds the background term
+    // separately (:531-534). Only its dot product with this pixel's dL/dC is ever used, so ONE scalar carries it:
+    //   Sd_i = sum_{k behind i} alpha_k T_k (c_k . dL/dC)  +  T_final (bg . dL/dC),
+    //   dL/dalpha_i = T_i (c_i . dL/dC) - Sd_i / (1 - alpha_i)          (same quantity, 19 instead of 36 VALU ops)
+    float Sd = T_final * (bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2);
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
     // nothing behind the deepest last_contributor of this wave's 64 pixels can matter to this wave
     int wave_last = last_contributor;
@@ -353,12 +357,12 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
         bool more = true;
         while (more) {
             float v[64];
-#pragma unroll
-            for (int q = 0; q < 64; q++) v[q] = 0.f;
+            v[63] = 0.f;                                         // pad: 7 x 9 = 63 values
             int jv = -1;                                         // lane g remembers the batch entry of group slot g
             bool any_slot = false;
 #pragma unroll
             for (int g = 0; g < GROUP_G; g++) {
+                bool filled = false;
                 while (more) {
                     while (m == 0 && chunk < 3) {
                         chunk++;
@@ -376,26 +380,24 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                     bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
                     hit = hit && (pos < last_contributor);       // backward.cu:486-488
                     if (!__any(hit)) continue;                   // wave-uniform: try the next entry for this slot
-                    if (hit) {
-                        // 1/(1-alpha) once, as a hardware reciprocal (1 ulp; 1-alpha is in [0.01, 1])
-                        const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
-                        Tr = Tr * rinv;
-                        const float dchannel_dcolor = alpha * Tr;
-                        const float c0 = b.z, c1 = b.w, c2 = s_c[j];
-                        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0;
-                        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c1;
-                        acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c2;
-                        float dL_dalpha = (c0 - acc0) * dpx0 + (c1 - acc1) * dpx1 + (c2 - acc2) * dpx2;
+                    {
+                        // branch-free: a pixel that does not blend this Gaussian runs the same instructions with
+                        // alpha = G = 0, which leaves T and Sd untouched and makes all nine terms exactly 0
+                        const float a_eff = hit ? alpha : 0.f, G_eff = hit ? G : 0.f;
+                        // 1/(1-alpha) once, as a hardware reciprocal (1 ulp; 1-alpha is in [0.01, 1]; rcp(1) == 1)
+                        const float rinv = __builtin_amdgcn_rcpf(1.f - a_eff);
+                        Tr = Tr * rinv;                              // transmittance in front of this Gaussian
+                        const float dchannel_dcolor = a_eff * Tr;
+                        const float cd = fmaf(s_c[j], dpx2, fmaf(b.w, dpx1, b.z * dpx0));
                         v[g * NPART + 0] = dchannel_dcolor * dpx0;
                         v[g * NPART + 1] = dchannel_dcolor * dpx1;
                         v[g * NPART + 2] = dchannel_dcolor * dpx2;
-                        dL_dalpha *= Tr;
-                        last_alpha = alpha;
-                        dL_dalpha += (-T_final * rinv) * bg_dot;     // backward.cu:531-534
+                        const float dL_dalpha = fmaf(Tr, cd, -(rinv * Sd));
+                        Sd = fmaf(dchannel_dcolor, cd, Sd);
                         // raw moments of w = G*dL_dalpha about the Gaussian's mean; the per-Gaussian linear maps to
                         // dL_dmean2D / dL_dconic / dL_dopacity (backward.cu:538-554) are applied ONCE per Gaussian,
                         // after the sum over pixels and tiles, in backward_preprocess.hip
-                        const float w = G * dL_dalpha;
+                        const float w = G_eff * dL_dalpha;
                         const float wx = w * dx, wy = w * dy;
                         v[g * NPART + 3] = w;
                         v[g * NPART + 4] = wx;
@@ -405,8 +407,12 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                         v[g * NPART + 8] = wy * dy;
                     }
                     if (lane == g) jv = j;
-                    any_slot = true;
+                    any_slot = filled = true;
                     break;
+                }
+                if (!filled) {                                   // list exhausted: this slot contributes nothing
+#pragma unroll
+                    for (int q = 0; q < NPART; q++) v[g * NPART + q] = 0.f;
                 }
             }
             if (!any_slot) break;
