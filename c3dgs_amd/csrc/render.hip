@@ -274,7 +274,7 @@ __device__ __forceinline__ float transpose_reduce_64(float* v, int lane)
     return __uint_as_float(s2[0]) + __uint_as_float(s2[1]);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_used,
                        const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
                        const float* __restrict__ bg, const float* __restrict__ final_Ts,
@@ -288,7 +288,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     __shared__ float s_c[BATCH];
     __shared__ uint32_t s_slot[BATCH];
     __shared__ unsigned long long s_mask[4][4];      // [quadrant][staging wave]
-    __shared__ float s_part[4][BATCH][NPART];
+    __shared__ float s_part[2][BATCH][NPART];         // one plane per wave PAIR (see the flush below)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = tile % gx, ty = tile / gx;
@@ -344,7 +344,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             if (lane == 0) s_mask[q][wave] = bm;
         }
 #pragma unroll
-        for (int w = 0; w < 4; w++)
+        for (int w = 0; w < 2; w++)
 #pragma unroll
             for (int q = 0; q < NPART; q++) s_part[w][tid][q] = 0.f;
         __syncthreads();
@@ -418,14 +418,17 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             if (!any_slot) break;
             const float total = transpose_reduce_64(v, lane);
             const int myj = __shfl(jv, my_g);                    // batch entry of the slot this lane's value belongs to
-            if (my_idx < GROUP_G * NPART && myj >= 0) s_part[wave][myj][my_c] = total;
+            // LDS float add into the plane this wave shares with ONE other wave: every (entry, term) receives at most
+            // one add per wave, and a + b == b + a, so the result does not depend on which wave arrives first
+            if (my_idx < GROUP_G * NPART && myj >= 0)
+                __hip_atomic_fetch_add(&s_part[wave >> 1][myj][my_c], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
         if (tid < cnt) {
             float* dst = partials + (size_t)s_slot[tid] * NPART;
 #pragma unroll
             for (int q = 0; q < NPART; q++)
-                dst[q] = (s_part[0][tid][q] + s_part[1][tid][q]) + (s_part[2][tid][q] + s_part[3][tid][q]);
+                dst[q] = s_part[0][tid][q] + s_part[1][tid][q];      // (w0 + w1) + (w2 + w3): fixed order, reproducible
             touched[s_slot[tid]] = 1;
         }
     }
