@@ -103,6 +103,7 @@ PROTOTYPES = {
     "c3dgs_get_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(ImageLayout)]),
     "c3dgs_backward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "c3dgs_profile_enable": (C.c_int, [C.c_int]),
+    "c3dgs_profile_only": (C.c_int, [C.c_char_p]),
     "c3dgs_profile_read": (C.c_int, [C.POINTER(StageTime), C.c_int]),
     "c3dgs_last_error": (C.c_char_p, []),
     "c3dgs_abi_version": (C.c_int, []),
@@ -137,7 +138,9 @@ def check(rc):
         raise RuntimeError((msg or b"unknown error").decode("utf-8", "replace"))
 
 
-def profile_enable(on=True):
+def profile_enable(on=True, only=None):
+    """Bracket stage launches with HIP events; `only` = one stage name to keep the queue cost to that kernel."""
+    check(lib().c3dgs_profile_only(only.encode() if only else None))
     lib().c3dgs_profile_enable(1 if on else 0)
 
 

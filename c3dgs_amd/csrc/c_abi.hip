@@ -24,12 +24,13 @@ static const char* kStageNames[ST_COUNT] = { "mark_visible", "preprocess", "dept
 struct ProfRec { int stage; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
+static int g_prof_only = -1;        // >= 0: bracket only this stage (two events per launch of ONE kernel)
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
 
 struct StageTimer {
     bool on; int stage; hipStream_t s; hipEvent_t a{}, b{};
-    StageTimer(int stage_, hipStream_t s_) : on(g_prof_on), stage(stage_), s(s_)
+    StageTimer(int stage_, hipStream_t s_) : on(g_prof_on && (g_prof_only < 0 || g_prof_only == stage_)), stage(stage_), s(s_)
     {
         if (!on) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -48,6 +49,22 @@ struct StageTimer {
         g_prof_recs.push_back({ stage, a, b });
     }
 };
+
+// pinned 4-byte landing pad + event for the forward's single device->host read (one per calling thread)
+struct HostRead {
+    uint32_t* pinned = nullptr;
+    hipEvent_t ev{};
+    HostRead()
+    {
+        if (hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault) != hipSuccess) { pinned = nullptr; return; }
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(pinned); pinned = nullptr; }
+    }
+};
+static HostRead& host_read()
+{
+    static thread_local HostRead h;
+    return h;
+}
 
 static int validate(const c3dgs_raster_params* p, bool indexed, bool is_backward)
 {
@@ -112,19 +129,28 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
 
     { StageTimer t_(ST_PREPROCESS, s); launch_preprocess(p, g, radii, s); }          // K2 / K2i
     C3DGS_STAGE("preprocess", p.debug, s);
+    // The one device->host read of the forward (K4, num_rendered) is issued as EARLY as its value exists: R is the last
+    // element of the id-order scan, which does not depend on the depth sort. The copy lands in pinned memory behind an
+    // event while the depth sort and the depth-order scan are already queued, so the GPU keeps working while the host
+    // waits, sizes the binning buffer and queues the rest (the reference blocks the stream at this point,
+    // rasterizer_impl.cu:279).
+    // id-order scan: the backward's per-instance slots are laid out by Gaussian id so that the per-Gaussian kernel
+    // (threads in id order) reads them coalesced
+    { StageTimer t_(ST_SCAN, s);
+      C3DGS_HIP_TRY(run_scan_by_id(g.scan_temp, g.scan_temp_bytes, g.tiles_touched, g.inst_offset, P, s)); }
+    C3DGS_STAGE("scan", p.debug, s);
+    HostRead& hr = host_read();
+    if (!hr.pinned) return fail(C3DGS_E_HIP, "pinned host buffer allocation failed");
+    C3DGS_HIP_TRY(hipMemcpyAsync(hr.pinned, g.inst_offset + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    C3DGS_HIP_TRY(hipEventRecord(hr.ev, s));
     { StageTimer t_(ST_DEPTH_SORT, s);                                               // binning stage 1: P Gaussians by depth
       C3DGS_HIP_TRY(run_depth_sort(g.scan_temp, g.scan_temp_bytes, g.depth_keys, g.depth_keys_sorted, g.ids, g.depth_order, P, s)); }
     C3DGS_STAGE("depth_sort", p.debug, s);
     { StageTimer t_(ST_SCAN, s);                                                     // K3, in depth order
       C3DGS_HIP_TRY(run_scan_in_order(g.scan_temp, g.scan_temp_bytes, g.depth_order, g.tiles_touched, g.sorted_offsets, P, s)); }
     C3DGS_STAGE("scan", p.debug, s);
-    // second scan in ID order: the backward's per-instance slots are laid out by Gaussian id so that the per-Gaussian
-    // kernel (threads in id order) reads them coalesced
-    { StageTimer t_(ST_SCAN, s);
-      C3DGS_HIP_TRY(run_scan_by_id(g.scan_temp, g.scan_temp_bytes, g.tiles_touched, g.inst_offset, P, s)); }
-    uint32_t R_u = 0;                                                                // K4: the one host sync
-    C3DGS_HIP_TRY(hipMemcpyAsync(&R_u, g.sorted_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    C3DGS_HIP_TRY(hipStreamSynchronize(s));
+    C3DGS_HIP_TRY(hipEventSynchronize(hr.ev));
+    const uint32_t R_u = *hr.pinned;
     if (R_u > 0x7fffffffu) return fail(C3DGS_E_INVALID, "num_rendered overflows int32");
     const int R = (int)R_u;
     *num_rendered = R;
@@ -209,6 +235,16 @@ int c3dgs_profile_enable(int on)
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
     return C3DGS_OK;
+}
+
+int c3dgs_profile_only(const char* stage_name)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_only = -1;
+    if (!stage_name || !*stage_name) return C3DGS_OK;
+    for (int i = 0; i < ST_COUNT; i++)
+        if (std::strcmp(stage_name, kStageNames[i]) == 0) { g_prof_only = i; return C3DGS_OK; }
+    return fail(C3DGS_E_INVALID, std::string("profile_only: unknown stage ") + stage_name);
 }
 
 int c3dgs_profile_read(c3dgs_stage_time* out, int capacity)

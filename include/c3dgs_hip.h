@@ -299,6 +299,10 @@ typedef struct c3dgs_stage_time {
     int64_t count;
 } c3dgs_stage_time;
 int c3dgs_profile_enable(int on);
+/* Restrict the event pairs to ONE stage (by the name c3dgs_profile_read reports, e.g. "render_backward"); NULL or "" =
+ * every stage. Every event pair costs a few microseconds of queue time, so a timed region brackets only the kernel
+ * it needs. */
+int c3dgs_profile_only(const char* stage_name);
 int c3dgs_profile_read(c3dgs_stage_time* out, int capacity);
 
 const char* c3dgs_last_error(void);
