@@ -24,6 +24,13 @@
 #define C3DGS_ABLATE_SHMATH 0
 #endif
 
+#ifndef C3DGS_BWD_CH
+#define C3DGS_BWD_CH 128
+#endif
+#ifndef C3DGS_BWD_WAVES
+#define C3DGS_BWD_WAVES 4   // waves per SIMD the register allocator must reach (128 VGPRs); measured: 3 -> 0.62 ms, 4 -> 0.54, 5 -> 0.60
+#endif
+
 namespace c3dgs {
 
 struct BwdArgs {
@@ -113,7 +120,11 @@ __device__ __forceinline__ void sh_backward(const float* c, float* dst, int M, c
 }
 
 template <int DEG, bool INDEXED>
-__global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs a)
+__global__ void __launch_bounds__(256)
+#if C3DGS_BWD_WAVES
+__attribute__((amdgpu_waves_per_eu(C3DGS_BWD_WAVES, C3DGS_BWD_WAVES)))
+#endif
+backward_preprocess_kernel(const BwdArgs a)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const size_t si = (size_t)i;
@@ -125,12 +136,11 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
     // (MI355X_MICROARCH.md, Global float atomics: ~17x below the contiguous rate). Instead every lane parks its
     // factors in LDS and the wave then walks its 64 Gaussians together: one atomic instruction per Gaussian whose
     // lanes cover that Gaussian's contiguous gradient row (up to 48 floats = 192 B for SH).
-    __shared__ float s_basis[INDEXED ? 256 : 1][NB + 1];
     __shared__ float s_g[INDEXED ? 256 : 1][3];
-    __shared__ int64_t s_row[INDEXED ? 256 : 1];
+    __shared__ int32_t s_row[INDEXED ? 256 : 1];      // codebook rows fit int32 (SHS, GS are int32 in the ABI)
     __shared__ float s_ds[INDEXED ? 256 : 1][3];
     __shared__ float s_dq[INDEXED ? 256 : 1][4];
-    __shared__ int64_t s_gi[INDEXED ? 256 : 1];
+    __shared__ int32_t s_gi[INDEXED ? 256 : 1];
     if (INDEXED) { s_row[threadIdx.x] = -1; s_gi[threadIdx.x] = -1; }
 
     bool live = i < a.P && a.radii[i] > 0;
@@ -140,8 +150,14 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
     // the wave's largest Gaussian and pay a dependent HBM latency per slot; instead the wave streams its range
     // through LDS in chunks with coalesced, independent loads (skipping never-written slots by their flag byte)
     // and every lane then adds up its own run from LDS. Fixed order -> still bitwise reproducible.
-    constexpr int CH = 128;
-    __shared__ float s_stage[4][CH][PARTIAL_FLOATS];
+    constexpr int CH = C3DGS_BWD_CH;
+    // one LDS region per wave, used twice: first as the staging area of the partial sums [CH][9], later (indexed variant)
+    // as the wave's 64 rows of SH basis values [64][NB+1] for the cooperative scatter-add. A wave only ever touches its
+    // own region, so wave-level fences order the two uses.
+    constexpr int WBUF = (CH * PARTIAL_FLOATS > 64 * (NB + 1)) ? CH * PARTIAL_FLOATS : 64 * (NB + 1);
+    __shared__ float s_buf[4][WBUF];
+#define s_stage(w, sl, q) s_buf[w][(sl) * PARTIAL_FLOATS + (q)]
+#define s_basis(t, k) s_buf[(t) >> 6][((t) & 63) * (NB + 1) + (k)]
     __shared__ uint8_t s_wr[4][CH];
     bool any_written = false;            // did ANY pixel of ANY tile blend this Gaussian?
     float acc[PARTIAL_FLOATS];
@@ -164,7 +180,7 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
                     const bool wr = a.touched[c0 + sl] != 0;
                     const float* src = a.partials + (size_t)(c0 + sl) * PARTIAL_FLOATS;
 #pragma unroll
-                    for (int q = 0; q < PARTIAL_FLOATS; q++) s_stage[wv][sl][q] = wr ? src[q] : 0.f;
+                    for (int q = 0; q < PARTIAL_FLOATS; q++) s_stage(wv, sl, q) = wr ? src[q] : 0.f;
                     s_wr[wv][sl] = wr ? 1 : 0;
                 }
             }
@@ -174,7 +190,7 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
             const uint32_t lo = max(start_, c0), hi = min(end_, c0 + n);
             for (uint32_t sl = lo; sl < hi; sl++) {
 #pragma unroll
-                for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] += s_stage[wv][sl - c0][q];
+                for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] += s_stage(wv, sl - c0, q);
                 any_written |= s_wr[wv][sl - c0] != 0;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -326,9 +342,9 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
         dmean[0] += add[0]; dmean[1] += add[1]; dmean[2] += add[2];
         if (INDEXED && o.dL_dsh) {
 #pragma unroll
-            for (int k = 0; k < NB; k++) s_basis[threadIdx.x][k] = basis[k];
+            for (int k = 0; k < NB; k++) s_basis(threadIdx.x, k) = basis[k];
             s_g[threadIdx.x][0] = g[0]; s_g[threadIdx.x][1] = g[1]; s_g[threadIdx.x][2] = g[2];
-            s_row[threadIdx.x] = (int64_t)row;
+            s_row[threadIdx.x] = (int32_t)row;
         }
     }
     if (o.dL_dmeans3D) { o.dL_dmeans3D[3 * si] = dmean[0]; o.dL_dmeans3D[3 * si + 1] = dmean[1]; o.dL_dmeans3D[3 * si + 2] = dmean[2]; }
@@ -369,7 +385,7 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
         if (INDEXED) {                       // backward_indexed.cu:255-262, 276-281 (scatter-add below)
             s_ds[threadIdx.x][0] = d_s[0] * sf; s_ds[threadIdx.x][1] = d_s[1] * sf; s_ds[threadIdx.x][2] = d_s[2] * sf;
             s_dq[threadIdx.x][0] = dq[0]; s_dq[threadIdx.x][1] = dq[1]; s_dq[threadIdx.x][2] = dq[2]; s_dq[threadIdx.x][3] = dq[3];
-            s_gi[threadIdx.x] = (int64_t)gi;
+            s_gi[threadIdx.x] = (int32_t)gi;
             if (o.dL_dscale_factors) o.dL_dscale_factors[si] = d_s[0] * sc[0] + d_s[1] * sc[1] + d_s[2] * sc[2];
         } else {
             if (o.dL_dscales) { o.dL_dscales[3 * si] = d_s[0]; o.dL_dscales[3 * si + 1] = d_s[1]; o.dL_dscales[3 * si + 2] = d_s[2]; }
@@ -386,10 +402,10 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
         if (o.dL_dsh && a.sh && !C3DGS_ABLATE_SH) {
             const int k = lane / 3, ch = lane - 3 * k;
             for (int j = 0; j < 64; j++) {
-                const int64_t row = s_row[wbase + j];            // wave-uniform
+                const int32_t row = s_row[wbase + j];            // wave-uniform
                 if (row < 0) continue;
                 if (lane < NB * 3)
-                    atomicAdd(o.dL_dsh + (size_t)row * a.M * 3 + lane, s_basis[wbase + j][k] * s_g[wbase + j][ch]);
+                    atomicAdd(o.dL_dsh + (size_t)row * a.M * 3 + lane, s_basis(wbase + j, k) * s_g[wbase + j][ch]);
             }
         }
         if (a.scales && !C3DGS_ABLATE_GS) {
@@ -397,14 +413,14 @@ __global__ void __launch_bounds__(256) backward_preprocess_kernel(const BwdArgs 
 #pragma unroll
                 for (int it = 0; it < 3; it++) {
                     const int q = it * 64 + lane, j = q / 3, c = q - 3 * j;
-                    const int64_t gi = s_gi[wbase + j];
+                    const int32_t gi = s_gi[wbase + j];
                     if (gi >= 0) atomicAdd(o.dL_dscales + 3 * (size_t)gi + c, s_ds[wbase + j][c]);
                 }
             if (o.dL_drotations)
 #pragma unroll
                 for (int it = 0; it < 4; it++) {
                     const int q = it * 64 + lane, j = q >> 2, c = q & 3;
-                    const int64_t gi = s_gi[wbase + j];
+                    const int32_t gi = s_gi[wbase + j];
                     if (gi >= 0) atomicAdd(o.dL_drotations + 4 * (size_t)gi + c, s_dq[wbase + j][c]);
                 }
         }
@@ -442,5 +458,8 @@ void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* rad
     }
 #undef C3DGS_LAUNCH
 }
+
+#undef s_stage
+#undef s_basis
 
 } // namespace c3dgs
