@@ -158,43 +158,81 @@ backward_preprocess_kernel(const BwdArgs a)
     __shared__ float s_buf[4][WBUF];
 #define s_stage(w, sl, q) s_buf[w][(sl) * PARTIAL_FLOATS + (q)]
 #define s_basis(t, k) s_buf[(t) >> 6][((t) & 63) * (NB + 1) + (k)]
-    __shared__ uint8_t s_wr[4][CH];
+    // Only ~1/4 of the slots were ever written (the blend kernel stops at each tile's saturation point), so the wave
+    // first reads the FLAG bytes of a whole sweep of FG*64 slots (independent byte loads, one wait), turns them into
+    // per-group ballots + running counts, and stages only the WRITTEN slots, compacted: entry e of the sweep = the e-th
+    // written slot. A lane's own run [start, end) maps to the contiguous entry range [below(start), below(end)), so the
+    // summation loop touches no flags and one pass usually covers the wave's whole range.
+    constexpr int FG = 8;
+    __shared__ unsigned long long s_fl[4][FG];
+    __shared__ uint32_t s_pre[4][FG + 1];
     bool any_written = false;            // did ANY pixel of ANY tile blend this Gaussian?
     float acc[PARTIAL_FLOATS];
 #pragma unroll
     for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] = 0.f;
     {
         const int lane_ = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const unsigned long long lt_mask = (1ull << lane_) - 1ull;
         const int ic = min(i, a.P - 1);                       // lanes past P clamp to the last Gaussian (empty run)
         const uint32_t end_ = a.inst_offset[ic];
         uint32_t start_ = (ic == 0) ? 0u : a.inst_offset[ic - 1];
         if (i >= a.P) start_ = end_;
         const uint32_t w_begin = __builtin_amdgcn_readfirstlane(start_);
         const uint32_t w_end = __builtin_amdgcn_readlane(end_, 63);
-        for (uint32_t c0 = w_begin; c0 < (C3DGS_ABLATE_STAGE ? w_begin : w_end); c0 += CH) {
-            const uint32_t n = min((uint32_t)CH, w_end - c0);
+        for (uint32_t base = w_begin; base < (C3DGS_ABLATE_STAGE ? w_begin : w_end); base += FG * 64) {
+            const uint32_t nsl = min((uint32_t)(FG * 64), w_end - base);
+            uint32_t fbits = 0;                               // bit g: slot base + 64 g + lane was written
 #pragma unroll
-            for (int k = 0; k < CH / 64; k++) {
-                const uint32_t sl = (uint32_t)(k * 64 + lane_);
-                if (sl < n) {
-                    const bool wr = a.touched[c0 + sl] != 0;
-                    const float* src = a.partials + (size_t)(c0 + sl) * PARTIAL_FLOATS;
-#pragma unroll
-                    for (int q = 0; q < PARTIAL_FLOATS; q++) s_stage(wv, sl, q) = wr ? src[q] : 0.f;
-                    s_wr[wv][sl] = wr ? 1 : 0;
-                }
+            for (int g = 0; g < FG; g++) {
+                const uint32_t sl = (uint32_t)(g * 64 + lane_);
+                if (sl < nsl && a.touched[base + sl] != 0) fbits |= 1u << g;
             }
+            uint32_t W = 0;                                   // wave-uniform running count of written slots
+#pragma unroll
+            for (int g = 0; g < FG; g++) {
+                const unsigned long long bm = __ballot((fbits >> g) & 1u);
+                if (lane_ == 0) { s_fl[wv][g] = bm; s_pre[wv][g] = W; }
+                W += (uint32_t)__popcll(bm);
+            }
+            if (W == 0) continue;                             // nothing in this sweep was ever blended
+            if (lane_ == 0) s_pre[wv][FG] = W;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t lo = max(start_, c0), hi = min(end_, c0 + n);
-            for (uint32_t sl = lo; sl < hi; sl++) {
+            auto below = [&](uint32_t x) -> uint32_t {        // written slots of this sweep before slot offset x
+                const uint32_t g = x >> 6;
+                if (g >= (uint32_t)FG) return s_pre[wv][FG];
+                return s_pre[wv][g] + (uint32_t)__popcll(s_fl[wv][g] & ((1ull << (x & 63u)) - 1ull));
+            };
+            const uint32_t lo = min(max(start_, base), base + nsl) - base, hi = min(max(end_, base), base + nsl) - base;
+            const uint32_t clo = below(lo), chi = below(hi);
+            any_written |= chi > clo;
+            for (uint32_t p0 = 0; p0 < W; p0 += CH) {
 #pragma unroll
-                for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] += s_stage(wv, sl - c0, q);
-                any_written |= s_wr[wv][sl - c0] != 0;
+                for (int g = 0; g < FG; g++) {
+                    const uint32_t pre_g = __builtin_amdgcn_readfirstlane(s_pre[wv][g]);
+                    const uint32_t pre_n = __builtin_amdgcn_readfirstlane(s_pre[wv][g + 1]);
+                    if (pre_n <= p0 || pre_g >= p0 + CH) continue;                  // wave-uniform
+                    if ((fbits >> g) & 1u) {
+                        const uint32_t e = pre_g + (uint32_t)__popcll(s_fl[wv][g] & lt_mask);
+                        if (e >= p0 && e < p0 + CH) {
+                            const float* src = a.partials + (size_t)(base + g * 64 + lane_) * PARTIAL_FLOATS;
+#pragma unroll
+                            for (int q = 0; q < PARTIAL_FLOATS; q++) s_stage(wv, e - p0, q) = src[q];
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t c_hi = min(chi, p0 + CH);
+                for (uint32_t c = max(clo, p0); c < c_hi; c++) {
+#pragma unroll
+                    for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] += s_stage(wv, c - p0, q);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
     }
     // A Gaussian none of whose tile instances was ever blended (it sits behind every pixel's saturation point: the
