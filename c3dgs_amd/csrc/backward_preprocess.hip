@@ -27,6 +27,9 @@
 #ifndef C3DGS_BWD_CH
 #define C3DGS_BWD_CH 128
 #endif
+#ifndef C3DGS_BWD_FG
+#define C3DGS_BWD_FG 8
+#endif
 #ifndef C3DGS_BWD_WAVES
 #define C3DGS_BWD_WAVES 4   // waves per SIMD the register allocator must reach (128 VGPRs); measured: 3 -> 0.62 ms, 4 -> 0.54, 5 -> 0.60
 #endif
@@ -163,7 +166,7 @@ backward_preprocess_kernel(const BwdArgs a)
     // per-group ballots + running counts, and stages only the WRITTEN slots, compacted: entry e of the sweep = the e-th
     // written slot. A lane's own run [start, end) maps to the contiguous entry range [below(start), below(end)), so the
     // summation loop touches no flags and one pass usually covers the wave's whole range.
-    constexpr int FG = 8;
+    constexpr int FG = C3DGS_BWD_FG;
     __shared__ unsigned long long s_fl[4][FG];
     __shared__ uint32_t s_pre[4][FG + 1];
     bool any_written = false;            // did ANY pixel of ANY tile blend this Gaussian?
