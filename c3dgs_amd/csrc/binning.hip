@@ -33,7 +33,9 @@ size_t scan_temp_bytes(int P)
     if (c > a) a = c;
     (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
                                     (uint32_t*)nullptr, (size_t)P, 0u, 32u);
-    const size_t m = a > b ? a : b;
+    size_t m = a > b ? a : b;
+    const size_t os = onesweep_depth_temp_bytes(P);               // the hand-written sort shares the same scratch region
+    if (os > m) m = os;
     return m < 256 ? 256 : m;
 }
 
@@ -42,12 +44,15 @@ size_t sort_temp_bytes(int R, int end_bit)
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint16_t*)nullptr, (uint16_t*)nullptr,
                                     (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)R, 0u, (unsigned)end_bit);
+    const size_t os = onesweep_tile_temp_bytes(R, end_bit);
+    if (os > bytes) bytes = os;
     return bytes < 256 ? 256 : bytes;
 }
 
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
                           uint32_t* vout, int P, hipStream_t s)
 {
+    if (onesweep_enabled()) return onesweep_depth_sort(temp, temp_bytes, kin, kout, vin, vout, P, s);
     return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 0u, 32u, s);
 }
 
@@ -66,6 +71,7 @@ hipError_t run_scan_by_id(void* temp, size_t temp_bytes, const uint32_t* tiles_t
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin,
                          uint32_t* vout, int R, int end_bit, hipStream_t s)
 {
+    if (onesweep_enabled()) return onesweep_tile_sort(temp, temp_bytes, kin, kout, vin, vout, R, end_bit, s);
     return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)R, 0u, (unsigned)end_bit, s);
 }
 

@@ -148,6 +148,14 @@ hipError_t run_scan_in_order(void* temp, size_t temp_bytes, const uint32_t* orde
 hipError_t run_scan_by_id(void* temp, size_t temp_bytes, const uint32_t* tiles_touched, uint32_t* out, int P, hipStream_t s);
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin,
                          uint32_t* vout, int R, int end_bit, hipStream_t s);
+// radix_sort.hip (hand-written onesweep; C3DGS_SORT_ROCPRIM=1 selects the rocPRIM path of binning.hip instead)
+bool onesweep_enabled();
+size_t onesweep_depth_temp_bytes(int P);
+size_t onesweep_tile_temp_bytes(int R, int end_bit);
+hipError_t onesweep_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                               int P, hipStream_t s);
+hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin, uint32_t* vout,
+                              int R, int end_bit, hipStream_t s);
 // render.hip
 void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                            const float* bg, float* out_color, hipStream_t s);
