@@ -42,7 +42,7 @@ struct BwdArgs {
     const float* cov3D_precomp; const int64_t* sh_indices; const int64_t* g_indices;
     const float* view; const float* proj; const float* campos;
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
-    const int32_t* radii; const uint32_t* tiles_touched; const uint32_t* inst_offset; const uint8_t* clamped; const float4* splat;
+    const int32_t* radii; const uint32_t* tiles_touched; const uint32_t* inst_offset; const uint32_t* block_base; const uint8_t* clamped; const float4* splat;
     const float* partials; const uint8_t* touched;
     c3dgs_raster_grads g;
 };
@@ -177,8 +177,9 @@ backward_preprocess_kernel(const BwdArgs a)
         const int lane_ = threadIdx.x & 63, wv = threadIdx.x >> 6;
         const unsigned long long lt_mask = (1ull << lane_) - 1ull;
         const int ic = min(i, a.P - 1);                       // lanes past P clamp to the last Gaussian (empty run)
-        const uint32_t end_ = a.inst_offset[ic];
-        uint32_t start_ = (ic == 0) ? 0u : a.inst_offset[ic - 1];
+        // global slot offsets = per-workgroup inclusive offsets of the forward + block_base[] (preprocess.hip)
+        const uint32_t end_ = a.inst_offset[ic] + a.block_base[ic >> 8];
+        uint32_t start_ = (ic == 0) ? 0u : a.inst_offset[ic - 1] + a.block_base[(ic - 1) >> 8];
         if (i >= a.P) start_ = end_;
         const uint32_t w_begin = __builtin_amdgcn_readfirstlane(start_);
         const uint32_t w_end = __builtin_amdgcn_readlane(end_, 63);
@@ -481,7 +482,7 @@ void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* rad
     a.focal_y = p.H / (2.0f * p.tan_fovy);
     a.focal_x = p.W / (2.0f * p.tan_fovx);
     a.scale_modifier = p.scale_modifier;
-    a.radii = radii; a.tiles_touched = g.tiles_touched; a.inst_offset = g.inst_offset; a.clamped = g.clamped; a.splat = g.splat;
+    a.radii = radii; a.tiles_touched = g.tiles_touched; a.inst_offset = g.inst_offset; a.block_base = g.block_base; a.clamped = g.clamped; a.splat = g.splat;
     a.partials = partials; a.touched = touched; a.g = gr;
     const dim3 grid((p.P + 255) / 256), block(256);
     const bool indexed = p.sh_indices != nullptr || p.g_indices != nullptr;

@@ -26,11 +26,9 @@ using OrderedTilesIt = rocprim::transform_iterator<const uint32_t*, TilesOf, uin
 
 size_t scan_temp_bytes(int P)
 {
-    size_t a = 0, b = 0, c = 0;
+    size_t a = 0, b = 0;
     OrderedTilesIt it((const uint32_t*)nullptr, TilesOf{ nullptr });
     (void)rocprim::inclusive_scan(nullptr, a, it, (uint32_t*)nullptr, (size_t)P, rocprim::plus<uint32_t>());
-    (void)rocprim::inclusive_scan(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)P, rocprim::plus<uint32_t>());
-    if (c > a) a = c;
     (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
                                     (uint32_t*)nullptr, (size_t)P, 0u, 32u);
     size_t m = a > b ? a : b;
@@ -61,11 +59,6 @@ hipError_t run_scan_in_order(void* temp, size_t temp_bytes, const uint32_t* orde
 {
     OrderedTilesIt it(order, TilesOf{ tiles_touched });
     return rocprim::inclusive_scan(temp, temp_bytes, it, out, (size_t)P, rocprim::plus<uint32_t>(), s);
-}
-
-hipError_t run_scan_by_id(void* temp, size_t temp_bytes, const uint32_t* tiles_touched, uint32_t* out, int P, hipStream_t s)
-{
-    return rocprim::inclusive_scan(temp, temp_bytes, tiles_touched, out, (size_t)P, rocprim::plus<uint32_t>(), s);
 }
 
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin,

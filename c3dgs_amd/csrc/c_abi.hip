@@ -127,21 +127,16 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     if (!geom_base) return fail(C3DGS_E_ALLOC, "geometry buffer allocation failed");
     const GeomPtrs g = geom_ptrs(geom_base, P);
 
-    { StageTimer t_(ST_PREPROCESS, s); launch_preprocess(p, g, radii, s); }          // K2 / K2i
+    // K2 / K2i, with the id-order scan of tiles_touched folded in (per-workgroup offsets + block_base[])
+    { StageTimer t_(ST_PREPROCESS, s); launch_preprocess(p, g, radii, s); }
     C3DGS_STAGE("preprocess", p.debug, s);
     // The one device->host read of the forward (K4, num_rendered) is issued as EARLY as its value exists: R is the last
-    // element of the id-order scan, which does not depend on the depth sort. The copy lands in pinned memory behind an
-    // event while the depth sort and the depth-order scan are already queued, so the GPU keeps working while the host
-    // waits, sizes the binning buffer and queues the rest (the reference blocks the stream at this point,
-    // rasterizer_impl.cu:279).
-    // id-order scan: the backward's per-instance slots are laid out by Gaussian id so that the per-Gaussian kernel
-    // (threads in id order) reads them coalesced
-    { StageTimer t_(ST_SCAN, s);
-      C3DGS_HIP_TRY(run_scan_by_id(g.scan_temp, g.scan_temp_bytes, g.tiles_touched, g.inst_offset, P, s)); }
-    C3DGS_STAGE("scan", p.debug, s);
+    // entry of block_base[]. The copy lands in pinned memory behind an event while the depth sort and the depth-order
+    // scan are already queued, so the GPU keeps working while the host waits, sizes the binning buffer and queues the
+    // rest (the reference blocks the stream at this point, rasterizer_impl.cu:279).
     HostRead& hr = host_read();
     if (!hr.pinned) return fail(C3DGS_E_HIP, "pinned host buffer allocation failed");
-    C3DGS_HIP_TRY(hipMemcpyAsync(hr.pinned, g.inst_offset + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    C3DGS_HIP_TRY(hipMemcpyAsync(hr.pinned, g.block_base + (P + 255) / 256, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     C3DGS_HIP_TRY(hipEventRecord(hr.ev, s));
     { StageTimer t_(ST_DEPTH_SORT, s);                                               // binning stage 1: P Gaussians by depth
       C3DGS_HIP_TRY(run_depth_sort(g.scan_temp, g.scan_temp_bytes, g.depth_keys, g.depth_keys_sorted, g.ids, g.depth_order, P, s)); }
@@ -214,7 +209,7 @@ static int backward_impl(const c3dgs_raster_params* pp, bool indexed, const int3
     if (R > 0) {
         const BinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), R, W, H);
         { StageTimer t_(ST_RENDER_BWD, s);
-          launch_render_backward(W, H, img, b.point_list, g.splat, p.background, dL_dout_color, partials, touched, s); } // K10
+          launch_render_backward(W, H, img, b.point_list, g.splat, g.block_base, p.background, dL_dout_color, partials, touched, s); } // K10
         C3DGS_STAGE("render_backward", p.debug, s);
     }
     { StageTimer t_(ST_BWD_PREPROCESS, s); launch_backward_preprocess(p, radii, g, partials, touched, *grads, s); } // K11 + K12(i)

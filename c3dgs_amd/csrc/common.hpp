@@ -72,6 +72,7 @@ inline void geom_layout(int P, c3dgs_geom_layout* L)
     L->inst_offset = o;       o = align_up(o + p * 4);
     L->rects = o;             o = align_up(o + p * 8);
     L->clamped = o;           o = align_up(o + p);
+    L->block_base = o;        o = align_up(o + ((p + 255) / 256 + 1) * 4);
     L->scan_temp = o;         L->scan_temp_bytes = scan_temp_bytes((int)p);
     o = align_up(o + L->scan_temp_bytes);
     L->total_bytes = o;
@@ -104,7 +105,7 @@ inline void image_layout(int W, int H, c3dgs_image_layout* L)
 struct GeomPtrs {
     float4* splat; float* depths; uint32_t* tiles_touched; uint32_t* depth_keys; uint32_t* ids; uint32_t* depth_keys_sorted;
     uint32_t* depth_order; uint32_t* sorted_offsets; uint32_t* inst_offset; uint16_t* rects;
-    uint8_t* clamped; void* scan_temp; size_t scan_temp_bytes;
+    uint8_t* clamped; uint32_t* block_base; void* scan_temp; size_t scan_temp_bytes;
 };
 struct BinPtrs {
     uint16_t* keys_unsorted; uint32_t* values_unsorted; uint16_t* keys_sorted; uint32_t* point_list;
@@ -119,7 +120,7 @@ inline GeomPtrs geom_ptrs(void* base, int P)
     return { (float4*)(b + L.splat), (float*)(b + L.depths), (uint32_t*)(b + L.tiles_touched), (uint32_t*)(b + L.depth_keys),
              (uint32_t*)(b + L.ids), (uint32_t*)(b + L.depth_keys_sorted), (uint32_t*)(b + L.depth_order),
              (uint32_t*)(b + L.sorted_offsets), (uint32_t*)(b + L.inst_offset), (uint16_t*)(b + L.rects),
-             (uint8_t*)(b + L.clamped), (void*)(b + L.scan_temp), L.scan_temp_bytes };
+             (uint8_t*)(b + L.clamped), (uint32_t*)(b + L.block_base), (void*)(b + L.scan_temp), L.scan_temp_bytes };
 }
 inline BinPtrs bin_ptrs(void* base, int R, int W, int H)
 {
@@ -145,7 +146,6 @@ hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, ui
                           uint32_t* vout, int P, hipStream_t s);
 hipError_t run_scan_in_order(void* temp, size_t temp_bytes, const uint32_t* order, const uint32_t* tiles_touched,
                              uint32_t* out, int P, hipStream_t s);
-hipError_t run_scan_by_id(void* temp, size_t temp_bytes, const uint32_t* tiles_touched, uint32_t* out, int P, hipStream_t s);
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin,
                          uint32_t* vout, int R, int end_bit, hipStream_t s);
 // radix_sort.hip (hand-written onesweep; C3DGS_SORT_ROCPRIM=1 selects the rocPRIM path of binning.hip instead)
@@ -160,7 +160,7 @@ hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin
 void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                            const float* bg, float* out_color, hipStream_t s);
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
-                            const float* bg, const float* dL_dpix, float* partials,
+                            const uint32_t* block_base, const float* bg, const float* dL_dpix, float* partials,
                             uint8_t* touched, hipStream_t s);
 // backward_preprocess.hip
 void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* radii, const GeomPtrs& g,

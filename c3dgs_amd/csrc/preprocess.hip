@@ -73,18 +73,30 @@ struct PreArgs {
     int prefiltered, clamp_color;
     int32_t* radii; float4* splat; float* depths; uint32_t* tiles_touched; uint16_t* rects; uint8_t* clamped;
     uint32_t* depth_keys; uint32_t* ids;
+    uint32_t* inst_offset; uint32_t* block_total;   // two-level id-order scan
 };
 
+// The id-order scan of tiles_touched (where a Gaussian's backward partial-sum slots live; its total is num_rendered) is
+// split in two levels so that no separate P-sized scan pass and no scattered "stamp" pass are needed: this kernel scans
+// inside each 256-Gaussian workgroup (inst_offset = inclusive offset WITHIN the workgroup, record word 9 = exclusive one)
+// and emits the workgroup totals; scan_blocks_kernel turns the ~P/256 totals into block_base[]. Consumers add
+// block_base[id >> 8].
 template <int DEG>
 __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.P) return;
+    __shared__ uint32_t s_wsum[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int i = blockIdx.x * 256 + t;
+    const bool in_range = i < a.P;
 
     int32_t out_radius = 0;
     uint32_t out_tiles = 0;
     uint32_t out_key = 0xffffffffu;            // culled Gaussians sort behind every visible one
-    do {
+    bool alive = false;
+    float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0;
+    float rgb2 = 0.f;
+    uint32_t rect_lo = 0, rect_hi = 0;
+    if (in_range) do {
         const f3 p = { a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2] };
         const f3 p_view = xform4x3(p, a.view);
         if (!a.prefiltered && p_view.z <= 0.01f) break;           // auxiliary.h:156
@@ -157,6 +169,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
             }
         }
 
+        alive = true;
         out_radius = (int32_t)my_radius;
         out_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
         out_key = __float_as_uint(p_view.z);
@@ -164,17 +177,63 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
         a.clamped[i] = clamp_bits;
         uint16_t* rc = a.rects + 4 * (size_t)i;
         rc[0] = (uint16_t)x0; rc[1] = (uint16_t)y0; rc[2] = (uint16_t)x1; rc[3] = (uint16_t)y1;
-        float4* rec = a.splat + 3 * (size_t)i;
-        rec[0] = make_float4(pix, piy, conic_a, conic_b);
-        rec[1] = make_float4(conic_c, a.opacities[i], rgb[0], rgb[1]);
-        rec[2] = make_float4(rgb[2], 0.f, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
-                             __uint_as_float((uint32_t)x1 | ((uint32_t)y1 << 16)));
+        rec0 = make_float4(pix, piy, conic_a, conic_b);
+        rec1 = make_float4(conic_c, a.opacities[i], rgb[0], rgb[1]);
+        rgb2 = rgb[2];
+        rect_lo = (uint32_t)x0 | ((uint32_t)y0 << 16);
+        rect_hi = (uint32_t)x1 | ((uint32_t)y1 << 16);
     } while (false);
 
+    // ---- id-order scan of tiles_touched within the workgroup
+    uint32_t incl = out_tiles;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += s_wsum[w];
+    const uint32_t my_incl = woff + incl;
+    if (t == 255) a.block_total[blockIdx.x] = my_incl;
+    if (!in_range) return;
+    if (alive) {
+        float4* rec = a.splat + 3 * (size_t)i;
+        rec[0] = rec0;
+        rec[1] = rec1;
+        // word 9: first backward partial-sum slot of this Gaussian, relative to block_base[i >> 8]
+        rec[2] = make_float4(rgb2, __uint_as_float(my_incl - out_tiles), __uint_as_float(rect_lo), __uint_as_float(rect_hi));
+    }
+    a.inst_offset[i] = my_incl;
     a.radii[i] = out_radius;
     a.tiles_touched[i] = out_tiles;
     a.depth_keys[i] = out_key;
     a.ids[i] = (uint32_t)i;
+}
+
+// exclusive scan of the workgroup totals, in place: base[b] = instances of all Gaussians before workgroup b;
+// base[nb] = num_rendered. One workgroup; nb = P/256 is a few thousand to a few ten-thousand.
+__global__ void __launch_bounds__(1024) scan_blocks_kernel(int nb, uint32_t* __restrict__ base)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < nb; c0 += 1024) {
+        const int idx = c0 + t;
+        const uint32_t v = idx < nb ? base[idx] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        uint32_t off = s_carry;
+        for (int w = 0; w < wave; w++) off += s_w[w];
+        if (idx < nb) base[idx] = off + incl - v;
+        __syncthreads();
+        if (t == 1023) s_carry = off + incl;
+        __syncthreads();
+    }
+    if (t == 0) base[nb] = s_carry;
 }
 
 void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, hipStream_t s)
@@ -192,6 +251,8 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
     a.scale_modifier = p.scale_modifier; a.prefiltered = p.prefiltered; a.clamp_color = p.clamp_color;
     a.radii = radii; a.splat = g.splat; a.depths = g.depths; a.tiles_touched = g.tiles_touched; a.rects = g.rects;
     a.clamped = g.clamped; a.depth_keys = g.depth_keys; a.ids = g.ids;
+    a.inst_offset = g.inst_offset;
+    a.block_total = g.block_base;     // totals in, exclusive bases out (scan_blocks_kernel)
     const dim3 grid((p.P + 255) / 256), block(256);
     const int deg = p.colors_precomp ? 0 : p.D;
     switch (deg) {
@@ -200,11 +261,11 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
         case 2: preprocess_kernel<2><<<grid, block, 0, s>>>(a); break;
         default: preprocess_kernel<3><<<grid, block, 0, s>>>(a); break;
     }
+    scan_blocks_kernel<<<1, 1024, 0, s>>>((int)grid.x, g.block_base);
 }
 
 // ---- K5: one (tile, Gaussian) pair per Gaussian x tile, reference rasterizer_impl.cu:70-111, walked in
-// (depth, id) order (binning.hip explains why). Thread k handles the k-th nearest Gaussian. Also stamps the
-// id-ordered instance slot offset into the splat record (word 9) for the backward.
+// (depth, id) order (binning.hip explains why). Thread k handles the k-th nearest Gaussian.
 // Load-balanced expansion: a workgroup owns 256 consecutive Gaussians of the depth order, whose pairs form ONE
 // contiguous output range; its threads walk that range (coalesced 2-byte / 4-byte stores) and find the owning
 // Gaussian of each output by binary search over the 256 scan values in LDS. A thread-per-Gaussian loop (the
@@ -212,7 +273,7 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
 __global__ void __launch_bounds__(256)
 duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
                            const uint32_t* __restrict__ sorted_offsets, const uint16_t* __restrict__ rects,
-                           float4* __restrict__ splat, const uint32_t* __restrict__ inst_offset, uint16_t* __restrict__ keys,
+                           uint16_t* __restrict__ keys,
                            uint32_t* __restrict__ values, int grid_x)
 {
     __shared__ uint32_t s_end[256];      // inclusive scan value of each of the block's Gaussians
@@ -248,23 +309,11 @@ duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint
     }
 }
 
-// stamps the id-ordered exclusive instance offset (= first backward partial-sum slot) into the splat record
-__global__ void __launch_bounds__(256)
-stamp_slots_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ inst_offset,
-                   float4* __restrict__ splat)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P || tiles_touched[i] == 0) return;
-    const uint32_t slot0 = (i == 0) ? 0u : inst_offset[i - 1];
-    reinterpret_cast<float*>(splat + 3 * (size_t)i + 2)[1] = __uint_as_float(slot0);
-}
-
 void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, hipStream_t s)
 {
     if (P <= 0) return;
-    stamp_slots_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.tiles_touched, g.inst_offset, g.splat);
     duplicate_with_keys_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.depth_order, g.tiles_touched, g.sorted_offsets, g.rects,
-                                                               g.splat, g.inst_offset, b.keys_unsorted, b.values_unsorted, grid_x);
+                                                               b.keys_unsorted, b.values_unsorted, grid_x);
 }
 
 // ---- K8: reference rasterizer_impl.cu:116-138 (ranges pre-zeroed by the caller, :308)

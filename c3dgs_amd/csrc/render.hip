@@ -277,7 +277,7 @@ __device__ __forceinline__ float transpose_reduce_64(float* v, int lane)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_used,
                        const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
-                       const float* __restrict__ bg, const float* __restrict__ final_Ts,
+                       const uint32_t* __restrict__ block_base, const float* __restrict__ bg, const float* __restrict__ final_Ts,
                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                        float* __restrict__ partials, uint8_t* __restrict__ touched)
 {
@@ -335,7 +335,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             s_a[tid] = a; s_b[tid] = b; s_c[tid] = c.x;
             const uint32_t off = __float_as_uint(c.y), lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
             const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
-            s_slot[tid] = off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            s_slot[tid] = block_base[id >> 8] + off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
             qm = quadrant_mask(a, b, tile_x0, tile_y0);
         }
 #pragma unroll
@@ -435,12 +435,12 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
 }
 
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
-                            const float* bg, const float* dL_dpix, float* partials,
+                            const uint32_t* block_base, const float* bg, const float* dL_dpix, float* partials,
                             uint8_t* touched, hipStream_t s)
 {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     const int grid = ((T + 7) / 8) * 8;
-    render_backward_kernel<<<grid, 256, 0, s>>>(W, H, gx, T, img.ranges, img.tile_used, point_list, splat, bg, img.final_T,
+    render_backward_kernel<<<grid, 256, 0, s>>>(W, H, gx, T, img.ranges, img.tile_used, point_list, splat, block_base, bg, img.final_T,
                                                 img.n_contrib, dL_dpix, partials, touched);
 }
 

@@ -259,11 +259,12 @@ typedef struct c3dgs_geom_layout {   /* byte offsets into the geometry buffer fo
     size_t depth_keys_sorted; /* uint32[P]                                                 */
     size_t depth_order;    /* uint32[P] Gaussian ids in (depth, id) order                  */
     size_t sorted_offsets; /* uint32[P] inclusive scan of tiles_touched in depth order     */
-    size_t inst_offset;    /* uint32[P] inclusive scan of tiles_touched in ID order: backward slot of (i, tile) */
+    size_t inst_offset;    /* uint32[P] inclusive scan of tiles_touched in ID order WITHIN each 256-Gaussian group; + block_base[i>>8] = backward slot end of i */
     size_t rects;          /* uint16[4*P]: xmin, ymin, xmax, ymax (tile units)             */
     size_t clamped;        /* uint8[P] bit c set = channel c was clamped                   */
     size_t scan_temp;      /* rocPRIM scan / depth-sort temporary storage                  */
     size_t scan_temp_bytes;
+    size_t block_base;     /* uint32[ceil(P/256)+1] instances before each 256-Gaussian group; last = num_rendered */
 } c3dgs_geom_layout;
 
 typedef struct c3dgs_binning_layout { /* byte offsets into the binning buffer for R instances */
