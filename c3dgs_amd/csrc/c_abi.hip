@@ -168,7 +168,8 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
         C3DGS_STAGE("identify_ranges", p.debug, s);
     }
     { StageTimer t_(ST_RENDER_FWD, s);
-      launch_render_forward(W, H, img, b.point_list, g.splat, p.background, out_color, s); } // K9
+      // per-instance quadrant masks go to the (now idle) sort scratch: R bytes the backward reads instead of recomputing
+      launch_render_forward(W, H, img, b.point_list, g.splat, p.background, out_color, (uint8_t*)b.sort_temp, s); } // K9
     C3DGS_STAGE("render_forward", p.debug, s);
     return C3DGS_OK;
 }
@@ -209,7 +210,8 @@ static int backward_impl(const c3dgs_raster_params* pp, bool indexed, const int3
     if (R > 0) {
         const BinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), R, W, H);
         { StageTimer t_(ST_RENDER_BWD, s);
-          launch_render_backward(W, H, img, b.point_list, g.splat, g.block_base, p.background, dL_dout_color, partials, touched, s); } // K10
+          launch_render_backward(W, H, img, b.point_list, g.splat, g.block_base, p.background, dL_dout_color, partials, touched,
+                                 (const uint8_t*)b.sort_temp, s); } // K10
         C3DGS_STAGE("render_backward", p.debug, s);
     }
     { StageTimer t_(ST_BWD_PREPROCESS, s); launch_backward_preprocess(p, radii, g, partials, touched, *grads, s); } // K11 + K12(i)

@@ -158,10 +158,10 @@ hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin
                               int R, int end_bit, hipStream_t s);
 // render.hip
 void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
-                           const float* bg, float* out_color, hipStream_t s);
+                           const float* bg, float* out_color, uint8_t* qmask, hipStream_t s);
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                             const uint32_t* block_base, const float* bg, const float* dL_dpix, float* partials,
-                            uint8_t* touched, hipStream_t s);
+                            uint8_t* touched, const uint8_t* qmask, hipStream_t s);
 // backward_preprocess.hip
 void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* radii, const GeomPtrs& g,
                                 const float* partials, const uint8_t* touched, const c3dgs_raster_grads& gr, hipStream_t s);

@@ -92,7 +92,8 @@ __device__ __forceinline__ int tile_of_block(int b, int T)
 __global__ void __launch_bounds__(256)
 render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const float4* __restrict__ splat, const float* __restrict__ bg, float* __restrict__ out_color,
-                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_used)
+                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_used,
+                      uint8_t* __restrict__ qmask)
 {
     const int tile = tile_of_block(blockIdx.x, T);
     if (tile >= T || (blockIdx.x >> 3) >= ((T + 7) >> 3)) return;
@@ -129,6 +130,7 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
         const int buf = r & 1;
         s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc.x;
         const uint32_t qm = (r * BATCH + tid < n) ? quadrant_mask(ra, rb, tile_x0, tile_y0) : 0u;
+        if (r * BATCH + tid < n) qmask[range.x + r * BATCH + tid] = (uint8_t)qm;   // the backward reuses it (same test, ~100 VALU ops)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const unsigned long long bm = __ballot((qm >> q) & 1u);
@@ -185,12 +187,12 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
 }
 
 void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
-                           const float* bg, float* out_color, hipStream_t s)
+                           const float* bg, float* out_color, uint8_t* qmask, hipStream_t s)
 {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     const int grid = ((T + 7) / 8) * 8;
     render_forward_kernel<<<grid, 256, 0, s>>>(W, H, gx, T, img.ranges, point_list, splat, bg, out_color, img.final_T,
-                                               img.n_contrib, img.tile_used);
+                                               img.n_contrib, img.tile_used, qmask);
 }
 
 // ---------------------------------------------------------------- backward
@@ -279,7 +281,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                        const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
                        const uint32_t* __restrict__ block_base, const float* __restrict__ bg, const float* __restrict__ final_Ts,
                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-                       float* __restrict__ partials, uint8_t* __restrict__ touched)
+                       float* __restrict__ partials, uint8_t* __restrict__ touched, const uint8_t* __restrict__ qmask)
 {
     const int tile = tile_of_block(blockIdx.x, T);
     if (tile >= T || (blockIdx.x >> 3) >= ((T + 7) >> 3)) return;
@@ -315,7 +317,6 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     //   Sd_i = sum_{k behind i} alpha_k T_k (c_k . dL/dC)  +  T_final (bg . dL/dC),
     //   dL/dalpha_i = T_i (c_i . dL/dC) - Sd_i / (1 - alpha_i)          (same quantity, 19 instead of 36 VALU ops)
     float Sd = T_final * (bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2);
-    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
     // nothing behind the deepest last_contributor of this wave's 64 pixels can matter to this wave
     int wave_last = last_contributor;
 #pragma unroll
@@ -336,7 +337,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             const uint32_t off = __float_as_uint(c.y), lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
             const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
             s_slot[tid] = block_base[id >> 8] + off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-            qm = quadrant_mask(a, b, tile_x0, tile_y0);
+            qm = qmask[range.x + mypos];                          // written by the forward for every entry it staged
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -436,12 +437,12 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
 
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                             const uint32_t* block_base, const float* bg, const float* dL_dpix, float* partials,
-                            uint8_t* touched, hipStream_t s)
+                            uint8_t* touched, const uint8_t* qmask, hipStream_t s)
 {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     const int grid = ((T + 7) / 8) * 8;
     render_backward_kernel<<<grid, 256, 0, s>>>(W, H, gx, T, img.ranges, img.tile_used, point_list, splat, block_base, bg, img.final_T,
-                                                img.n_contrib, dL_dpix, partials, touched);
+                                                img.n_contrib, dL_dpix, partials, touched, qmask);
 }
 
 } // namespace c3dgs
