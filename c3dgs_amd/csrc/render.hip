@@ -24,6 +24,9 @@
 namespace c3dgs {
 
 constexpr int BATCH = 256;
+#ifndef C3DGS_FWD_CHECK
+#define C3DGS_FWD_CHECK 1
+#endif
 
 // alpha of one Gaussian at one pixel; the SAME instruction sequence in forward and backward so both
 // take identical skip decisions (explicit fma placement, independent of -ffp-contract).
@@ -147,8 +150,12 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
         }
         if (wave_done) continue;
         const uint32_t base = (uint32_t)(r * BATCH);
-        bool wave_all_done = false;
-        for (int c = 0; c < 4 && !wave_all_done; c++) {
+        for (int c = 0; c < 4; c++) {
+            // the wave's early-out is tested once per 64-entry chunk, not per Gaussian: finished pixels blend nothing
+            // either way, and the per-Gaussian test (ballot + scalar branch) cost more than the work it saved
+#if C3DGS_FWD_CHECK != 0
+            if (__all(done)) break;
+#endif
             unsigned long long m = uniform_u64(s_mask[buf][wave][c]);   // scalar: only Gaussians that can reach this quadrant
             while (m) {
                 const int j = c * 64 + __builtin_ctzll(m);
@@ -168,7 +175,9 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
                 Tr = blend ? test_T : Tr;
                 last_contributor = blend ? base + (uint32_t)j + 1u : last_contributor;
                 done = done || stop;
-                if (__all(done)) { wave_all_done = true; break; }
+#if C3DGS_FWD_CHECK == 2
+                if (__all(done)) break;
+#endif
             }
         }
     }
@@ -285,10 +294,11 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
 {
     const int tile = tile_of_block(blockIdx.x, T);
     if (tile >= T || (blockIdx.x >> 3) >= ((T + 7) >> 3)) return;
-    __shared__ float4 s_a[BATCH];
-    __shared__ float4 s_b[BATCH];
-    __shared__ float s_c[BATCH];
+    __shared__ float4 s_a[BATCH + 1];                 // entry BATCH is a sentinel with opacity 0 (blends nothing)
+    __shared__ float4 s_b[BATCH + 1];
+    __shared__ float s_c[BATCH + 1];
     __shared__ uint32_t s_slot[BATCH];
+    __shared__ uint16_t s_list[4][(BATCH / GROUP_G + 2) * 8];   // per wave: its candidates of the batch, 7 per 16-byte row
     __shared__ unsigned long long s_mask[4][4];      // [quadrant][staging wave]
     __shared__ float s_part[2][BATCH][NPART];         // one plane per wave PAIR (see the flush below)
 
@@ -305,6 +315,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     const int used = min(n, (int)tile_used[tile]);
     if (used <= 0) return;
     const int rounds = (used + BATCH - 1) / BATCH;
+    if (tid == 0) { s_a[BATCH] = make_float4(0, 0, 0, 0); s_b[BATCH] = make_float4(0, 0, 0, 0); s_c[BATCH] = 0.f; }
 
     const float T_final = inside ? final_Ts[pix] : 0.f;         // backward.cu:441-447
     float Tr = T_final;
@@ -352,71 +363,74 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
 
         const int cnt = min(BATCH, used - r * BATCH);
         const int pos0 = used - 1 - r * BATCH;                   // position of batch entry j is pos0 - j
-        // iterator over the batch entries this wave has to look at (scalar state)
-        int chunk = -1;
-        unsigned long long m = 0;
-        bool more = true;
-        while (more) {
+        // This wave's candidates of the batch, compacted into LDS once: 7 entry indices per 16-byte row (one row = one
+        // reduction group), padded with the sentinel. The group loop below then has NO data-dependent control flow: one
+        // broadcast row read, seven fixed slots, one reduction. (A slot whose Gaussian turns out to touch no pixel of the
+        // wave -- 3.6 % on the bench scene -- adds zeros; testing for it per Gaussian cost more than it saved.)
+        int nw = 0;
+        {
+            const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                unsigned long long m = uniform_u64(s_mask[wave][c]);
+                // entries with pos >= wave_last (j <= pos0 - wave_last) are behind every pixel of this wave
+                const int jmin = pos0 - wave_last + 1 - c * 64;
+                if (jmin >= 64) m = 0; else if (jmin > 0) m &= ~0ull << jmin;
+                if ((m >> lane) & 1ull) {
+                    const int p = nw + (int)__popcll(m & lt), row = p / GROUP_G;
+                    s_list[wave][row * 8 + (p - row * GROUP_G)] = (uint16_t)(c * 64 + lane);
+                }
+                nw += (int)__popcll(m);
+            }
+            if (lane < GROUP_G) {
+                const int p = nw + lane, row = p / GROUP_G;
+                s_list[wave][row * 8 + (p - row * GROUP_G)] = (uint16_t)BATCH;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        for (int k = 0; k < nw; k += GROUP_G) {
+            const uint4 row = *reinterpret_cast<const uint4*>(&s_list[wave][(k / GROUP_G) * 8]);
+            const uint32_t rw[4] = { (uint32_t)__builtin_amdgcn_readfirstlane((int)row.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)row.y),
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)row.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)row.w) };
             float v[64];
             v[63] = 0.f;                                         // pad: 7 x 9 = 63 values
             int jv = -1;                                         // lane g remembers the batch entry of group slot g
-            bool any_slot = false;
 #pragma unroll
             for (int g = 0; g < GROUP_G; g++) {
-                bool filled = false;
-                while (more) {
-                    while (m == 0 && chunk < 3) {
-                        chunk++;
-                        m = uniform_u64(s_mask[wave][chunk]);
-                        // entries with pos >= wave_last (j <= pos0 - wave_last) are behind every pixel of this wave
-                        const int jmin = pos0 - wave_last + 1 - chunk * 64;
-                        if (jmin >= 64) m = 0; else if (jmin > 0) m &= ~0ull << jmin;
-                    }
-                    if (m == 0) { more = false; break; }
-                    const int j = chunk * 64 + __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int pos = pos0 - j;                    // 0-based position in the tile's list
-                    const float4 a = s_a[j], b = s_b[j];
-                    float dx, dy, G, alpha;
-                    bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
-                    hit = hit && (pos < last_contributor);       // backward.cu:486-488
-                    if (!__any(hit)) continue;                   // wave-uniform: try the next entry for this slot
-                    {
-                        // branch-free: a pixel that does not blend this Gaussian runs the same instructions with
-                        // alpha = G = 0, which leaves T and Sd untouched and makes all nine terms exactly 0
-                        const float a_eff = hit ? alpha : 0.f, G_eff = hit ? G : 0.f;
-                        // 1/(1-alpha) once, as a hardware reciprocal (1 ulp; 1-alpha is in [0.01, 1]; rcp(1) == 1)
-                        const float rinv = __builtin_amdgcn_rcpf(1.f - a_eff);
-                        Tr = Tr * rinv;                              // transmittance in front of this Gaussian
-                        const float dchannel_dcolor = a_eff * Tr;
-                        const float cd = fmaf(s_c[j], dpx2, fmaf(b.w, dpx1, b.z * dpx0));
-                        v[g * NPART + 0] = dchannel_dcolor * dpx0;
-                        v[g * NPART + 1] = dchannel_dcolor * dpx1;
-                        v[g * NPART + 2] = dchannel_dcolor * dpx2;
-                        const float dL_dalpha = fmaf(Tr, cd, -(rinv * Sd));
-                        Sd = fmaf(dchannel_dcolor, cd, Sd);
-                        // raw moments of w = G*dL_dalpha about the Gaussian's mean; the per-Gaussian linear maps to
-                        // dL_dmean2D / dL_dconic / dL_dopacity (backward.cu:538-554) are applied ONCE per Gaussian,
-                        // after the sum over pixels and tiles, in backward_preprocess.hip
-                        const float w = G_eff * dL_dalpha;
-                        const float wx = w * dx, wy = w * dy;
-                        v[g * NPART + 3] = w;
-                        v[g * NPART + 4] = wx;
-                        v[g * NPART + 5] = wy;
-                        v[g * NPART + 6] = wx * dx;
-                        v[g * NPART + 7] = wx * dy;
-                        v[g * NPART + 8] = wy * dy;
-                    }
-                    if (lane == g) jv = j;
-                    any_slot = filled = true;
-                    break;
-                }
-                if (!filled) {                                   // list exhausted: this slot contributes nothing
-#pragma unroll
-                    for (int q = 0; q < NPART; q++) v[g * NPART + q] = 0.f;
-                }
+                const int j = (int)((rw[g >> 1] >> ((g & 1) * 16)) & 0xffffu);
+                const int pos = pos0 - j;                        // 0-based position in the tile's list
+                const float4 a = s_a[j], b = s_b[j];
+                float dx, dy, G, alpha;
+                bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
+                hit = hit && (pos < last_contributor);           // backward.cu:486-488
+                // branch-free: a pixel that does not blend this Gaussian runs the same instructions with
+                // alpha = G = 0, which leaves T and Sd untouched and makes all nine terms exactly 0
+                const float a_eff = hit ? alpha : 0.f, G_eff = hit ? G : 0.f;
+                // 1/(1-alpha) once, as a hardware reciprocal (1 ulp; 1-alpha is in [0.01, 1]; rcp(1) == 1)
+                const float rinv = __builtin_amdgcn_rcpf(1.f - a_eff);
+                Tr = Tr * rinv;                                  // transmittance in front of this Gaussian
+                const float dchannel_dcolor = a_eff * Tr;
+                const float cd = fmaf(s_c[j], dpx2, fmaf(b.w, dpx1, b.z * dpx0));
+                v[g * NPART + 0] = dchannel_dcolor * dpx0;
+                v[g * NPART + 1] = dchannel_dcolor * dpx1;
+                v[g * NPART + 2] = dchannel_dcolor * dpx2;
+                const float dL_dalpha = fmaf(Tr, cd, -(rinv * Sd));
+                Sd = fmaf(dchannel_dcolor, cd, Sd);
+                // raw moments of w = G*dL_dalpha about the Gaussian's mean; the per-Gaussian linear maps to
+                // dL_dmean2D / dL_dconic / dL_dopacity (backward.cu:538-554) are applied ONCE per Gaussian,
+                // after the sum over pixels and tiles, in backward_preprocess.hip
+                const float w = G_eff * dL_dalpha;
+                const float wx = w * dx, wy = w * dy;
+                v[g * NPART + 3] = w;
+                v[g * NPART + 4] = wx;
+                v[g * NPART + 5] = wy;
+                v[g * NPART + 6] = wx * dx;
+                v[g * NPART + 7] = wx * dy;
+                v[g * NPART + 8] = wy * dy;
+                if (lane == g) jv = j < BATCH ? j : -1;
             }
-            if (!any_slot) break;
             const float total = transpose_reduce_64(v, lane);
             const int myj = __shfl(jv, my_g);                    // batch entry of the slot this lane's value belongs to
             // LDS float add into the plane this wave shares with ONE other wave: every (entry, term) receives at most
