@@ -24,9 +24,6 @@
 namespace c3dgs {
 
 constexpr int BATCH = 256;
-#ifndef C3DGS_FWD_CHECK
-#define C3DGS_FWD_CHECK 1
-#endif
 
 // alpha of one Gaussian at one pixel; the SAME instruction sequence in forward and backward so both
 // take identical skip decisions (explicit fma placement, independent of -ffp-contract).
@@ -100,9 +97,10 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
 {
     const int tile = tile_of_block(blockIdx.x, T);
     if (tile >= T || (blockIdx.x >> 3) >= ((T + 7) >> 3)) return;
-    __shared__ float4 s_a[2][BATCH];
-    __shared__ float4 s_b[2][BATCH];
-    __shared__ float s_c[2][BATCH];
+    __shared__ float4 s_a[2][BATCH + 1];             // entry BATCH of each buffer: sentinel with opacity 0 (blends nothing)
+    __shared__ float4 s_b[2][BATCH + 1];
+    __shared__ float s_c[2][BATCH + 1];
+    __shared__ uint16_t s_list[4][(BATCH / 8 + 2) * 8];   // per wave: its candidates of the batch, 8 per 16-byte row
     __shared__ int s_wdone[2][4];
     __shared__ unsigned long long s_mask[2][4][4];   // [buf][quadrant][staging wave]: which staged Gaussians reach it
     __shared__ uint32_t s_used;
@@ -115,6 +113,7 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     const float pxf = (float)px, pyf = (float)py;
     bool done = !inside;
     if (tid == 0) s_used = 0;
+    if (tid < 2) { s_a[tid][BATCH] = make_float4(0, 0, 0, 0); s_b[tid][BATCH] = make_float4(0, 0, 0, 0); s_c[tid][BATCH] = 0.f; }
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
     const uint2 range = ranges[tile];
@@ -150,22 +149,37 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
         }
         if (wave_done) continue;
         const uint32_t base = (uint32_t)(r * BATCH);
-        for (int c = 0; c < 4; c++) {
-            // the wave's early-out is tested once per 64-entry chunk, not per Gaussian: finished pixels blend nothing
-            // either way, and the per-Gaussian test (ballot + scalar branch) cost more than the work it saved
-#if C3DGS_FWD_CHECK != 0
+        // This wave's candidates of the batch, compacted into LDS once (8 entry indices per 16-byte row, padded with the
+        // sentinel): the blend loop then needs no bit scanning and no per-Gaussian scalar control flow.
+        int nw = 0;
+        {
+            const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const unsigned long long m = uniform_u64(s_mask[buf][wave][c]);   // Gaussians that can reach this quadrant
+                if ((m >> lane) & 1ull) s_list[wave][nw + (int)__popcll(m & lt)] = (uint16_t)(c * 64 + lane);
+                nw += (int)__popcll(m);
+            }
+            if (lane < 8) s_list[wave][nw + lane] = (uint16_t)BATCH;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        for (int k = 0; k < nw; k += 8) {
+            // the wave's early-out is tested once per row of 8, not per Gaussian: finished pixels blend nothing either
+            // way, and a per-Gaussian test (ballot + scalar branch) costs more than the work it saves
             if (__all(done)) break;
-#endif
-            unsigned long long m = uniform_u64(s_mask[buf][wave][c]);   // scalar: only Gaussians that can reach this quadrant
-            while (m) {
-                const int j = c * 64 + __builtin_ctzll(m);
-                m &= m - 1;
+            const uint4 row = *reinterpret_cast<const uint4*>(&s_list[wave][k]);
+            const uint32_t rw[4] = { (uint32_t)__builtin_amdgcn_readfirstlane((int)row.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)row.y),
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)row.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)row.w) };
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                const int j = (int)((rw[g >> 1] >> ((g & 1) * 16)) & 0xffffu);
                 const float4 a = s_a[buf][j], b = s_b[buf][j];
                 const float cblue = s_c[buf][j];
                 float dx, dy, G, alpha;
                 const bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
-                // branch-free blend (selects instead of nested exec-mask regions: the loop is co-limited by the
-                // scalar unit, and every divergent `if` costs several s_and_saveexec / s_or exec instructions)
+                // branch-free blend (selects instead of nested exec-mask regions)
                 const bool live_px = hit && !done;
                 const float test_T = Tr * (1.f - alpha);
                 const bool stop = live_px && test_T < 0.0001f;   // forward.cu:355-360: stop BEFORE blending this one
@@ -175,9 +189,6 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
                 Tr = blend ? test_T : Tr;
                 last_contributor = blend ? base + (uint32_t)j + 1u : last_contributor;
                 done = done || stop;
-#if C3DGS_FWD_CHECK == 2
-                if (__all(done)) break;
-#endif
             }
         }
     }
