@@ -296,7 +296,10 @@ __device__ __forceinline__ float transpose_reduce_64(float* v, int lane)
     return __uint_as_float(s2[0]) + __uint_as_float(s2[1]);
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef C3DGS_BWD_WPE
+#define C3DGS_BWD_WPE 5   // waves per SIMD the register allocator must reach (102 VGPRs); measured 3: 0.85 ms, 4: 0.745, 5: 0.707
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C3DGS_BWD_WPE, C3DGS_BWD_WPE)))
 render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_used,
                        const uint32_t* __restrict__ point_list, const float4* __restrict__ splat,
                        const uint32_t* __restrict__ block_base, const float* __restrict__ bg, const float* __restrict__ final_Ts,
