@@ -50,7 +50,7 @@ size_t sort_temp_bytes(int R, int end_bit)
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
                           uint32_t* vout, int P, hipStream_t s)
 {
-    if (onesweep_enabled()) return onesweep_depth_sort(temp, temp_bytes, kin, kout, vin, vout, P, s);
+    if (onesweep_enabled() && (size_t)P < ((size_t)1 << 30)) return onesweep_depth_sort(temp, temp_bytes, kin, kout, vin, vout, P, s);
     return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 0u, 32u, s);
 }
 
@@ -64,7 +64,7 @@ hipError_t run_scan_in_order(void* temp, size_t temp_bytes, const uint32_t* orde
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin,
                          uint32_t* vout, int R, int end_bit, hipStream_t s)
 {
-    if (onesweep_enabled()) return onesweep_tile_sort(temp, temp_bytes, kin, kout, vin, vout, R, end_bit, s);
+    if (onesweep_enabled() && (size_t)R < ((size_t)1 << 30)) return onesweep_tile_sort(temp, temp_bytes, kin, kout, vin, vout, R, end_bit, s);
     return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)R, 0u, (unsigned)end_bit, s);
 }
 

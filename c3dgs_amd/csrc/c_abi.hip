@@ -93,6 +93,8 @@ static int validate(const c3dgs_raster_params* p, bool indexed, bool is_backward
         return fail(C3DGS_E_INVALID, "non-indexed rasterizer: sh_indices / g_indices / scale_factors must be NULL");
     }
     if (tiles_x(p->W) > 65535 || tiles_y(p->H) > 65535) return fail(C3DGS_E_INVALID, "image too large for 16-bit tile coordinates");
+    if ((long long)tiles_x(p->W) * tiles_y(p->H) > 65536)       // tile ids are 16-bit sort keys (up to 4096 x 4096 pixels)
+        return fail(C3DGS_E_INVALID, "image has more than 65536 tiles (16-bit tile keys): at most 16.7 Mpixel");
     return C3DGS_OK;
 }
 

@@ -75,3 +75,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_image_larger_than_the_16_bit_tile_keys_is_rejected(L):
+    from c3dgs_amd import _lib
+    p = _lib.RasterParams()
+    p.P, p.W, p.H = 4, 7680, 4320                        # 480 x 270 = 129600 tiles
+    one = (C.c_float * 16)()
+    for name in ("background", "means3D", "sh", "opacities", "scales", "rotations", "viewmatrix", "projmatrix", "campos"):
+        setattr(p, name, C.addressof(one))
+    p.M, p.D = 16, 3
+    n = C.c_int32(0)
+    cb = _lib.RESIZE_FN(lambda u, b: 0)
+    rc = L.c3dgs_rasterize_gaussians(C.byref(p), cb, None, cb, None, cb, None, C.addressof(one), C.addressof(one), C.byref(n), None)
+    assert rc == 1 and b"65536 tiles" in L.c3dgs_last_error()
