@@ -430,6 +430,35 @@ class GaussianModel:
     def get_normalized_covariance(self, scaling_modifier=1, strip_sym=True):
         return _covariance(self.get_scaling_normalized, scaling_modifier, self.get_rotation, strip_sym)
 
+    # ---- what compress_gaussians needs (gaussian_model.py:1027-1059)
+    def mask_splats(self, mask):
+        with torch.no_grad():
+            keep = lambda t: None if t is None else t.detach()[mask].contiguous().requires_grad_(t.requires_grad)
+            self._xyz, self._opacity, self._scaling_factor = keep(self._xyz), keep(self._opacity), keep(self._scaling_factor)
+            if self.is_color_indexed:
+                self._feature_indices = self._feature_indices[mask].contiguous()
+            else:
+                self._features_dc, self._features_rest = keep(self._features_dc), keep(self._features_rest)
+            if self.is_gaussian_indexed:
+                self._gaussian_indices = self._gaussian_indices[mask].contiguous()
+            else:
+                self._scaling, self._rotation = keep(self._scaling), keep(self._rotation)
+
+    def set_color_indexed(self, features, indices):
+        self._feature_indices = indices.detach().to(self.device, torch.int64).contiguous()
+        self._features_dc = features[:, :1].detach().contiguous().requires_grad_(True)
+        self._features_rest = features[:, 1:].detach().contiguous().requires_grad_(True)
+        self.color_index_mode = ColorMode.ALL_INDEXED
+
+    def set_gaussian_indexed(self, rotation, scaling, indices):
+        self._gaussian_indices = indices.detach().to(self.device, torch.int64).contiguous()
+        self._rotation = rotation.detach().contiguous().requires_grad_(True)
+        self._scaling = scaling.detach().contiguous().requires_grad_(True)
+
+    def zero_grad(self):
+        for t in self.parameters():
+            t.grad = None
+
     # ---- on-disk payload (gaussian_model.py:505-623 save_npz, :625-720 load_npz, :997-1023 _sort_morton)
     def _sort_morton(self):
         from . import encode

@@ -79,3 +79,19 @@ def calc_importance(render_fn: Callable, features_dc: torch.Tensor, features_res
         num_pixels = int(npx.item())
     importance = torch.cat([accum1, accum2], 1).flatten(-2)
     return importance / num_pixels, accum3 / num_pixels
+
+
+def calc_importance_experimental(gaussians, cameras: Iterable, pipeline_params, silent: bool = True, use_gt: bool = False,
+                                 group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """compress.py:81-119 with the reference's signature (`scene` replaced by the iterable of cameras): the model's
+    own render() is used, with cov3d = unit-scale covariance x scaling_factor^2 and clamp_color=False."""
+    cov3d_scaled = gaussians.get_covariance().detach()
+    coeff = gaussians.get_scaling_factor.detach().square()
+    cov3d = (cov3d_scaled / coeff).requires_grad_(True)
+    background = torch.zeros(3, dtype=torch.float32, device=cov3d.device)
+
+    def render_fn(camera):
+        return gaussians.render(camera, pipeline_params, background, clamp_color=False, cov3d=cov3d * coeff)["render"]
+
+    return calc_importance(render_fn, gaussians._features_dc, gaussians._features_rest, cov3d, cameras, use_gt=use_gt,
+                           group=group)
