@@ -213,27 +213,25 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
 // base[nb] = num_rendered. One workgroup; nb = P/256 is a few thousand to a few ten-thousand.
 __global__ void __launch_bounds__(1024) scan_blocks_kernel(int nb, uint32_t* __restrict__ base)
 {
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_w[2][16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) s_carry = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < nb; c0 += 1024) {
+    uint32_t carry = 0;                                   // every thread tracks the running total itself
+    int buf = 0;
+    for (int c0 = 0; c0 < nb; c0 += 1024, buf ^= 1) {
         const int idx = c0 + t;
         const uint32_t v = idx < nb ? base[idx] : 0u;
         uint32_t incl = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-        if (lane == 63) s_w[wave] = incl;
-        __syncthreads();
-        uint32_t off = s_carry;
-        for (int w = 0; w < wave; w++) off += s_w[w];
+        if (lane == 63) s_w[buf][wave] = incl;
+        __syncthreads();                                  // one barrier per 1024 totals (s_w is double-buffered)
+        uint32_t off = carry, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const uint32_t x = s_w[buf][w]; if (w < wave) off += x; all += x; }
         if (idx < nb) base[idx] = off + incl - v;
-        __syncthreads();
-        if (t == 1023) s_carry = off + incl;
-        __syncthreads();
+        carry += all;
     }
-    if (t == 0) base[nb] = s_carry;
+    if (t == 0) base[nb] = carry;
 }
 
 void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, hipStream_t s)

@@ -118,34 +118,34 @@ qat_observe_kernel(const ObsJobs jobs, float* __restrict__ ws)
 }
 
 // MovingAverageMinMaxObserver.forward + _calculate_qparams (per_tensor_affine, qint8) for every observed module
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * C3DGS_FQ_COUNT)
 qat_finalize_kernel(const ObsJobs jobs, const float* __restrict__ ws, c3dgs_fq_state* __restrict__ state, float c)
 {
-    for (int t = 0; t < jobs.n; t++) {
-        const ObsJob job = jobs.j[t];
-        float lo = INFINITY, hi = -INFINITY;
-        for (int b = threadIdx.x; b < job.nblocks; b += 64) {
-            lo = fminf(lo, ws[(job.slot * OBS_MAXB + b) * 2]);
-            hi = fmaxf(hi, ws[(job.slot * OBS_MAXB + b) * 2 + 1]);
-        }
+    const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;          // one wave per observed module
+    if (t >= jobs.n) return;
+    const ObsJob job = jobs.j[t];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int b = lane; b < job.nblocks; b += 64) {
+        lo = fminf(lo, ws[(job.slot * OBS_MAXB + b) * 2]);
+        hi = fmaxf(hi, ws[(job.slot * OBS_MAXB + b) * 2 + 1]);
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
-        if (threadIdx.x == 0) {
-            c3dgs_fq_state s = state[job.slot];
-            if (s.min_val == INFINITY && s.max_val == -INFINITY) { s.min_val = lo; s.max_val = hi; }
-            else {
-                s.min_val = s.min_val + c * (lo - s.min_val);
-                s.max_val = s.max_val + c * (hi - s.max_val);
-            }
-            if (s.min_val == INFINITY && s.max_val == -INFINITY) { s.scale = 1.0f; s.zero_point = 0; }  // check_min_max_valid
-            else {
-                const float min_neg = fminf(s.min_val, 0.f), max_pos = fmaxf(s.max_val, 0.f);
-                s.scale = fmaxf((max_pos - min_neg) / 255.0f, FLT_EPSILON);
-                const int zp = -128 - (int)rintf(min_neg / s.scale);
-                s.zero_point = min(127, max(-128, zp));
-            }
-            state[job.slot] = s;
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    if (lane == 0) {
+        c3dgs_fq_state s = state[job.slot];
+        if (s.min_val == INFINITY && s.max_val == -INFINITY) { s.min_val = lo; s.max_val = hi; }
+        else {
+            s.min_val = s.min_val + c * (lo - s.min_val);
+            s.max_val = s.max_val + c * (hi - s.max_val);
         }
+        if (s.min_val == INFINITY && s.max_val == -INFINITY) { s.scale = 1.0f; s.zero_point = 0; }  // check_min_max_valid
+        else {
+            const float min_neg = fminf(s.min_val, 0.f), max_pos = fmaxf(s.max_val, 0.f);
+            s.scale = fmaxf((max_pos - min_neg) / 255.0f, FLT_EPSILON);
+            const int zp = -128 - (int)rintf(min_neg / s.scale);
+            s.zero_point = min(127, max(-128, zp));
+        }
+        state[job.slot] = s;
     }
 }
 
@@ -176,7 +176,7 @@ void launch_qat_observe(const c3dgs_qat_params& q, void* workspace, hipStream_t 
         add_job(J, nb, q.features_rest, SHS * 3 * (q.M - 1), ACT_IDENT, C3DGS_FQ_FEATURES_REST, 4);
     if (J.n == 0) return;
     qat_observe_kernel<<<nb, 256, 0, s>>>(J, (float*)workspace);
-    qat_finalize_kernel<<<1, 64, 0, s>>>(J, (const float*)workspace, q.state, q.averaging_constant);
+    qat_finalize_kernel<<<1, 64 * C3DGS_FQ_COUNT, 0, s>>>(J, (const float*)workspace, q.state, q.averaging_constant);
 }
 
 // ------------------------------------------------------------------------------------------- codebooks
@@ -557,7 +557,7 @@ void launch_fake_quantize(long long n, const float* x, c3dgs_fq_state* state, in
         int nb = 0;
         add_job(J, nb, x, n, ACT_IDENT, 0, 4);
         qat_observe_kernel<<<nb, 256, 0, s>>>(J, (float*)workspace);
-        qat_finalize_kernel<<<1, 64, 0, s>>>(J, (const float*)workspace, state, c);
+        qat_finalize_kernel<<<1, 64 * C3DGS_FQ_COUNT, 0, s>>>(J, (const float*)workspace, state, c);
     }
     const long long want = (n + 1023) / 1024;
     fq_elementwise_kernel<<<(int)(want > 8192 ? 8192 : want), 256, 0, s>>>(n, x, state, enabled, nullptr, out);

@@ -53,12 +53,14 @@ static size_t os_ctrl_bytes(size_t n, int passes)
     return align_up(((size_t)passes * OS_RADIX + (size_t)passes * os_blocks(n) * OS_RADIX + 64) * sizeof(uint32_t));
 }
 
-// all digit histograms in one read of the keys
+// all digit histograms in one read of the keys: 1024-thread workgroups (at most 512 of them, so the final flush stays a
+// few hundred atomics per global bin), four independent 16-byte loads in flight per thread
+constexpr int OS_HIST_BLOCK = 1024;
 template <class K>
-__global__ void __launch_bounds__(256) os_hist_kernel(const K* __restrict__ keys, size_t n, OsPlan plan, uint32_t* __restrict__ hist)
+__global__ void __launch_bounds__(OS_HIST_BLOCK) os_hist_kernel(const K* __restrict__ keys, size_t n, OsPlan plan, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t s_h[OS_MAX_PASSES][OS_RADIX];
-    for (int q = threadIdx.x; q < OS_MAX_PASSES * OS_RADIX; q += 256) (&s_h[0][0])[q] = 0;
+    for (int q = threadIdx.x; q < OS_MAX_PASSES * OS_RADIX; q += OS_HIST_BLOCK) (&s_h[0][0])[q] = 0;
     __syncthreads();
     constexpr int VEC = 16 / sizeof(K);                     // keys per 16-byte load
     const size_t nvec = n / VEC;
@@ -70,18 +72,24 @@ __global__ void __launch_bounds__(256) os_hist_kernel(const K* __restrict__ keys
             shift += plan.bits[p];
         }
     };
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
-        const uint4 v = k4[i];
+    auto add4 = [&](const uint4 v) {
         const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             if (sizeof(K) == 4) add(w[e]);
             else { add(w[e] & 0xffffu); add(w[e] >> 16); }
         }
+    };
+    const size_t stride = (size_t)gridDim.x * OS_HIST_BLOCK;
+    size_t i = (size_t)blockIdx.x * OS_HIST_BLOCK + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        const uint4 v0 = k4[i], v1 = k4[i + stride], v2 = k4[i + 2 * stride], v3 = k4[i + 3 * stride];
+        add4(v0); add4(v1); add4(v2); add4(v3);
     }
-    for (size_t i = nvec * VEC + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) add((uint32_t)keys[i]);
+    for (; i < nvec; i += stride) add4(k4[i]);
+    for (size_t j = nvec * VEC + (size_t)blockIdx.x * OS_HIST_BLOCK + threadIdx.x; j < n; j += stride) add((uint32_t)keys[j]);
     __syncthreads();
-    for (int q = threadIdx.x; q < plan.passes * OS_RADIX; q += 256) {
+    for (int q = threadIdx.x; q < plan.passes * OS_RADIX; q += OS_HIST_BLOCK) {
         const uint32_t v = (&s_h[0][0])[q];
         if (v) atomicAdd(&hist[q], v);
     }
@@ -257,8 +265,9 @@ static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, 
     for (int i = 0; i < 2; i++) { tk[i] = (K*)q; q += align_up(n * sizeof(K)); tv[i] = (uint32_t*)q; q += align_up(n * sizeof(uint32_t)); }
     hipError_t e = hipMemsetAsync(base, 0, ctrl, s);
     if (e != hipSuccess) return e;
-    const unsigned hb = (unsigned)std::min<size_t>((n + 256 * 64 - 1) / (256 * 64), 1024);
-    os_hist_kernel<K><<<hb, 256, 0, s>>>(kin, n, plan, hist);
+    const size_t nvec16 = n * sizeof(K) / 16 + 1;
+    const unsigned hb = (unsigned)std::min<size_t>((nvec16 + OS_HIST_BLOCK * 4 - 1) / (OS_HIST_BLOCK * 4), 512);
+    os_hist_kernel<K><<<hb, OS_HIST_BLOCK, 0, s>>>(kin, n, plan, hist);
     int shift = 0;
     for (int p = 0; p < plan.passes; p++) {
         const K* ki = p == 0 ? kin : tk[(p - 1) & 1];

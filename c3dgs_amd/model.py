@@ -230,7 +230,8 @@ class _QatGetters(torch.autograd.Function):
             visible, rank, V = vis
             V = int(V() if callable(V) else V)                # the one host read, deferred until here
         means3D = torch.empty(V, 3, **f32) if raw["xyz"] is not None else None
-        means2D = torch.zeros(V, 3, **f32) if screenspace is not None else None
+        # means2D only exists to carry a gradient back to `screenspace`: the rasterizer never reads its values
+        means2D = torch.empty(V, 3, **f32) if screenspace is not None else None
         opac = torch.empty(V, 1, **f32) if raw["opacity"] is not None else None
         sfac = torch.empty(V, 1, **f32) if raw["scaling_factor"] is not None else None
         sh_out = torch.empty(V, dtype=torch.int64, device=dev) if (sh_indices is not None and vis is not None) else None
