@@ -11,6 +11,7 @@ PyTorch is plumbing only here (device memory, streams, autograd bookkeeping); ev
 runs in libc3dgs_hip.so.  There is no CPU path: tensors must live on the GPU.
 """
 import ctypes as C
+import threading
 import math
 import weakref
 from types import SimpleNamespace
@@ -228,6 +229,12 @@ def _forward(indexed, background, means3D, colors, opacity, scales, scale_factor
     return int(num_rendered.value), out_color, radii, scratch.get("geom"), scratch.get("binning"), scratch.get("img")
 
 
+# Outputs the autograd wrappers do not need (gradients of ABSENT optional inputs) are neither allocated nor written:
+# dL_dcolors (12 B x P) and dL_dcov3D (24 B x P) are 108 MB of stores per 3M-Gaussian backward. The pybind-order
+# entry points (_C.*) keep returning every tensor like the reference.
+_SKIP = threading.local()
+
+
 def _backward(indexed, background, means3D, radii, colors, scales, scale_factors, rotations, scale_modifier, cov3D_precomp,
               viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geomBuffer, R, binningBuffer,
               imageBuffer, debug, sh_indices, g_indices):
@@ -247,9 +254,10 @@ def _backward(indexed, background, means3D, radii, colors, scales, scale_factors
     with torch.cuda.device(dev):
         dL_dmeans3D = torch.empty((P, 3), **opt)
         dL_dmeans2D = torch.empty((P, 3), **opt)
-        dL_dcolors = torch.empty((P, 3), **opt)
+        skip = getattr(_SKIP, "names", ())
+        dL_dcolors = None if "dL_dcolors" in skip else torch.empty((P, 3), **opt)
         dL_dopacity = torch.empty((P, 1), **opt)
-        dL_dcov3D = torch.empty((P, 6), **opt)
+        dL_dcov3D = None if "dL_dcov3D" in skip else torch.empty((P, 6), **opt)
         if indexed:
             dL_dsh = torch.empty((SHS, M, 3), **opt)       # zeroed + scatter-added inside the library
             dL_dscales = torch.empty((GS, 3), **opt)
@@ -263,8 +271,8 @@ def _backward(indexed, background, means3D, radii, colors, scales, scale_factors
             dL_drotations = torch.empty((P, 4), **opt) if t["scales"] is not None else torch.zeros((P, 4), **opt)
             dL_dscale_factors = None
         g = RasterGrads()
-        g.dL_dmeans2D, g.dL_dcolors, g.dL_dopacity = dL_dmeans2D.data_ptr(), dL_dcolors.data_ptr(), dL_dopacity.data_ptr()
-        g.dL_dmeans3D, g.dL_dcov3D = dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr()
+        g.dL_dmeans2D, g.dL_dcolors, g.dL_dopacity = dL_dmeans2D.data_ptr(), _ptr(dL_dcolors), dL_dopacity.data_ptr()
+        g.dL_dmeans3D, g.dL_dcov3D = dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D)
         g.dL_dsh = dL_dsh.data_ptr() if dL_dsh.numel() else None
         g.dL_dscales = dL_dscales.data_ptr() if dL_dscales.numel() else None
         g.dL_drotations = dL_drotations.data_ptr() if dL_drotations.numel() else None
@@ -390,8 +398,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, view, proj,
                 tanfovx, tanfovy, grad_out_color, sh, rs.sh_degree, campos, geomBuffer, ctx.num_rendered, binningBuffer,
                 imgBuffer, rs.debug)
-        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations) = _call_debug(_C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump")
+        _SKIP.names = tuple(n for n, t in (("dL_dcolors", colors_precomp), ("dL_dcov3D", cov3Ds_precomp)) if t is None or t.numel() == 0)
+        try:
+            (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+             grad_rotations) = _call_debug(_C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump")
+        finally:
+            _SKIP.names = ()
         return (grad_means3D, grad_means2D, _fit(grad_sh, sh), _fit(grad_colors_precomp, colors_precomp), grad_opacities,
                 _fit(grad_scales, scales), _fit(grad_rotations, rotations), _fit(grad_cov3Ds_precomp, cov3Ds_precomp),
                 None, None)
@@ -432,7 +444,11 @@ def _indexed_backward(ctx, grad_out_color):
     args = (rs.bg, means3D, radii, colors_precomp, scales, scale_factors, rotations, rs.scale_modifier, cov3Ds_precomp, view,
             proj, tanfovx, tanfovy, grad_out_color, sh, rs.sh_degree, campos, geomBuffer, ctx.num_rendered, binningBuffer,
             imgBuffer, rs.debug, sh_indices, g_indices)
-    out = _call_debug(_C.rasterize_gaussians_backward_indexed, args, rs.debug, "snapshot_bw.dump")
+    _SKIP.names = tuple(n for n, t in (("dL_dcolors", colors_precomp), ("dL_dcov3D", cov3Ds_precomp)) if t is None or t.numel() == 0)
+    try:
+        out = _call_debug(_C.rasterize_gaussians_backward_indexed, args, rs.debug, "snapshot_bw.dump")
+    finally:
+        _SKIP.names = ()
     return out, (extrinsic_vector, colors_precomp, means3D, scales, scale_factors, rotations, cov3Ds_precomp, sh)
 
 
