@@ -130,7 +130,7 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     const GeomPtrs g = geom_ptrs(geom_base, P);
 
     // K2 / K2i, with the id-order scan of tiles_touched folded in (per-workgroup offsets + block_base[])
-    { StageTimer t_(ST_PREPROCESS, s); launch_preprocess(p, g, radii, s); }
+    { StageTimer t_(ST_PREPROCESS, s); launch_preprocess(p, g, radii, img.ranges, s); }
     C3DGS_STAGE("preprocess", p.debug, s);
     // The one device->host read of the forward (K4, num_rendered) is issued as EARLY as its value exists: R is the last
     // entry of block_base[]. The copy lands in pinned memory behind an event while the depth sort and the depth-order
@@ -157,7 +157,6 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     if (!bin_base) return fail(C3DGS_E_ALLOC, "binning buffer allocation failed");
     const BinPtrs b = bin_ptrs(bin_base, R, W, H);
 
-    C3DGS_HIP_TRY(hipMemsetAsync(img.ranges, 0, (size_t)T * sizeof(uint2), s));      // K7
     if (R > 0) {
         { StageTimer t_(ST_DUPLICATE, s); launch_duplicate_with_keys(P, g, b, gx, s); } // K5
         C3DGS_STAGE("duplicate_with_keys", p.debug, s);
@@ -189,9 +188,18 @@ static int backward_impl(const c3dgs_raster_params* pp, bool indexed, const int3
 
     // codebook-sized outputs of the indexed variant are scatter-added: zero them here
     if (indexed) {
-        if (grads->dL_dsh && p.sh) C3DGS_HIP_TRY(hipMemsetAsync(grads->dL_dsh, 0, (size_t)p.SHS * p.M * 3 * sizeof(float), s));
-        if (grads->dL_dscales && p.scales) C3DGS_HIP_TRY(hipMemsetAsync(grads->dL_dscales, 0, (size_t)p.GS * 3 * sizeof(float), s));
-        if (grads->dL_drotations && p.scales) C3DGS_HIP_TRY(hipMemsetAsync(grads->dL_drotations, 0, (size_t)p.GS * 4 * sizeof(float), s));
+        const size_t n_sh = (grads->dL_dsh && p.sh) ? (size_t)p.SHS * p.M * 3 * sizeof(float) : 0;
+        const size_t n_rot = (grads->dL_drotations && p.scales) ? (size_t)p.GS * 4 * sizeof(float) : 0;
+        const size_t n_sc = (grads->dL_dscales && p.scales) ? (size_t)p.GS * 3 * sizeof(float) : 0;
+        char* a_sh = (char*)grads->dL_dsh; char* a_rot = (char*)grads->dL_drotations; char* a_sc = (char*)grads->dL_dscales;
+        if (n_sh && n_rot && n_sc && a_rot == a_sh + n_sh && a_sc == a_rot + n_rot) {
+            // the three tensors are carved from one allocation (c3dgs_amd/rasterizer.py does that): one fill launch
+            C3DGS_HIP_TRY(hipMemsetAsync(a_sh, 0, n_sh + n_rot + n_sc, s));
+        } else {
+            if (n_sh) C3DGS_HIP_TRY(hipMemsetAsync(a_sh, 0, n_sh, s));
+            if (n_sc) C3DGS_HIP_TRY(hipMemsetAsync(a_sc, 0, n_sc, s));
+            if (n_rot) C3DGS_HIP_TRY(hipMemsetAsync(a_rot, 0, n_rot, s));
+        }
     }
     if (P == 0) return C3DGS_OK;
     if (!radii || !geom_buffer || !image_buffer || !dL_dout_color || (R > 0 && !binning_buffer))

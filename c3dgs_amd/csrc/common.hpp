@@ -138,7 +138,7 @@ inline ImgPtrs img_ptrs(void* base, int W, int H)
 
 // preprocess.hip
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
-void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, hipStream_t s);
+void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, hipStream_t s);
 void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, hipStream_t s);
 void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, hipStream_t s);
 // binning.hip

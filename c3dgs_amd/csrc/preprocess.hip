@@ -74,6 +74,7 @@ struct PreArgs {
     int32_t* radii; float4* splat; float* depths; uint32_t* tiles_touched; uint16_t* rects; uint8_t* clamped;
     uint32_t* depth_keys; uint32_t* ids;
     uint32_t* inst_offset; uint32_t* block_total;   // two-level id-order scan
+    uint2* ranges; int T;                            // tile ranges, cleared here for identify_ranges (K7)
 };
 
 // The id-order scan of tiles_touched (where a Gaussian's backward partial-sum slots live; its total is num_rendered) is
@@ -88,6 +89,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int i = blockIdx.x * 256 + t;
     const bool in_range = i < a.P;
+    for (int q = i; q < a.T; q += gridDim.x * 256) a.ranges[q] = make_uint2(0u, 0u);   // replaces a memset launch (rasterizer_impl.cu:308)
 
     int32_t out_radius = 0;
     uint32_t out_tiles = 0;
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(1024) scan_blocks_kernel(int nb, uint32_t* __r
     if (t == 0) base[nb] = carry;
 }
 
-void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, hipStream_t s)
+void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, hipStream_t s)
 {
     if (p.P <= 0) return;
     PreArgs a;
@@ -251,6 +253,7 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
     a.clamped = g.clamped; a.depth_keys = g.depth_keys; a.ids = g.ids;
     a.inst_offset = g.inst_offset;
     a.block_total = g.block_base;     // totals in, exclusive bases out (scan_blocks_kernel)
+    a.ranges = ranges; a.T = a.gx * a.gy;
     const dim3 grid((p.P + 255) / 256), block(256);
     const int deg = p.colors_precomp ? 0 : p.D;
     switch (deg) {

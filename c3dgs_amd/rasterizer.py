@@ -259,9 +259,13 @@ def _backward(indexed, background, means3D, radii, colors, scales, scale_factors
         dL_dopacity = torch.empty((P, 1), **opt)
         dL_dcov3D = None if "dL_dcov3D" in skip else torch.empty((P, 6), **opt)
         if indexed:
-            dL_dsh = torch.empty((SHS, M, 3), **opt)       # zeroed + scatter-added inside the library
-            dL_dscales = torch.empty((GS, 3), **opt)
-            dL_drotations = torch.empty((GS, 4), **opt)
+            # zeroed + scatter-added inside the library; carved from ONE allocation (sh | rotations | scales, every start
+            # 16-byte aligned) so that the library clears them with a single fill
+            n_sh, n_rot, n_sc = SHS * M * 3, GS * 4, GS * 3
+            flat = torch.empty(n_sh + n_rot + n_sc, **opt)
+            dL_dsh = flat[:n_sh].view(SHS, M, 3)
+            dL_drotations = flat[n_sh:n_sh + n_rot].view(GS, 4)
+            dL_dscales = flat[n_sh + n_rot:].view(GS, 3)
             dL_dscale_factors = torch.empty((P, 1), **opt)
         else:
             # reference shapes (rasterize_points.cu:153-162): [P,M,3], [P,3], [P,4]; rows stay zero when the
