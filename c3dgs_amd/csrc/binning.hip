@@ -12,23 +12,13 @@
 // emission (= id) order that the reference's single stable sort yields, so the sorted point list is bit-identical
 // (asserted against the oracle). (The umbrella <rocprim/rocprim.hpp> does not compile on this ROCm install.)
 #include "common.hpp"
-#include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace c3dgs {
-
-struct TilesOf {
-    const uint32_t* tiles;
-    __host__ __device__ uint32_t operator()(uint32_t id) const { return tiles[id]; }
-};
-using OrderedTilesIt = rocprim::transform_iterator<const uint32_t*, TilesOf, uint32_t>;
 
 size_t scan_temp_bytes(int P)
 {
     size_t a = 0, b = 0;
-    OrderedTilesIt it((const uint32_t*)nullptr, TilesOf{ nullptr });
-    (void)rocprim::inclusive_scan(nullptr, a, it, (uint32_t*)nullptr, (size_t)P, rocprim::plus<uint32_t>());
     (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
                                     (uint32_t*)nullptr, (size_t)P, 0u, 32u);
     size_t m = a > b ? a : b;
@@ -47,18 +37,25 @@ size_t sort_temp_bytes(int R, int end_bit)
     return bytes < 256 ? 256 : bytes;
 }
 
-hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
-                          uint32_t* vout, int P, hipStream_t s)
+__global__ void __launch_bounds__(256)
+gather_u64_kernel(int n, const uint32_t* __restrict__ idx, const uint2* __restrict__ src, uint2* __restrict__ dst)
 {
-    if (onesweep_enabled() && (size_t)P < ((size_t)1 << 30)) return onesweep_depth_sort(temp, temp_bytes, kin, kout, vin, vout, P, s);
-    return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 0u, 32u, s);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
 }
 
-hipError_t run_scan_in_order(void* temp, size_t temp_bytes, const uint32_t* order, const uint32_t* tiles_touched,
-                             uint32_t* out, int P, hipStream_t s)
+// sorts (depth bits, id) and also delivers `rects_sorted[k]` = tile rectangle of the k-th nearest Gaussian (the one
+// per-Gaussian record the pair emission needs): the hand-written sort gathers it while scattering its last digit pass,
+// the rocPRIM path with one extra kernel
+hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
+                          uint32_t* vout, int P, const uint2* rects, uint2* rects_sorted, hipStream_t s)
 {
-    OrderedTilesIt it(order, TilesOf{ tiles_touched });
-    return rocprim::inclusive_scan(temp, temp_bytes, it, out, (size_t)P, rocprim::plus<uint32_t>(), s);
+    if (onesweep_enabled() && (size_t)P < ((size_t)1 << 30))
+        return onesweep_depth_sort(temp, temp_bytes, kin, kout, vin, vout, P, rects, rects_sorted, s);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 0u, 32u, s);
+    if (e != hipSuccess) return e;
+    gather_u64_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, vout, rects, rects_sorted);
+    return hipGetLastError();
 }
 
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin,

@@ -141,10 +141,10 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     C3DGS_HIP_TRY(hipMemcpyAsync(hr.pinned, g.block_base + (P + 255) / 256, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     C3DGS_HIP_TRY(hipEventRecord(hr.ev, s));
     { StageTimer t_(ST_DEPTH_SORT, s);                                               // binning stage 1: P Gaussians by depth
-      C3DGS_HIP_TRY(run_depth_sort(g.scan_temp, g.scan_temp_bytes, g.depth_keys, g.depth_keys_sorted, g.ids, g.depth_order, P, s)); }
+      C3DGS_HIP_TRY(run_depth_sort(g.scan_temp, g.scan_temp_bytes, g.depth_keys, g.depth_keys_sorted, g.ids, g.depth_order, P,
+                                   reinterpret_cast<const uint2*>(g.rects), g.sorted_offsets, s)); }
     C3DGS_STAGE("depth_sort", p.debug, s);
-    { StageTimer t_(ST_SCAN, s);                                                     // K3, in depth order
-      C3DGS_HIP_TRY(run_scan_in_order(g.scan_temp, g.scan_temp_bytes, g.depth_order, g.tiles_touched, g.sorted_offsets, P, s)); }
+    { StageTimer t_(ST_SCAN, s); launch_depth_order_scan(P, g, s); }                 // K3, in depth order (two-level)
     C3DGS_STAGE("scan", p.debug, s);
     C3DGS_HIP_TRY(hipEventSynchronize(hr.ev));
     const uint32_t R_u = *hr.pinned;

@@ -68,11 +68,12 @@ inline void geom_layout(int P, c3dgs_geom_layout* L)
     L->ids = o;               o = align_up(o + p * 4);
     L->depth_keys_sorted = o; o = align_up(o + p * 4);
     L->depth_order = o;       o = align_up(o + p * 4);
-    L->sorted_offsets = o;    o = align_up(o + p * 4);
+    L->sorted_offsets = o;    o = align_up(o + p * 8);
     L->inst_offset = o;       o = align_up(o + p * 4);
     L->rects = o;             o = align_up(o + p * 8);
     L->clamped = o;           o = align_up(o + p);
     L->block_base = o;        o = align_up(o + ((p + 255) / 256 + 1) * 4);
+    L->depth_base = o;        o = align_up(o + ((p + 255) / 256 + 1) * 4);
     L->scan_temp = o;         L->scan_temp_bytes = scan_temp_bytes((int)p);
     o = align_up(o + L->scan_temp_bytes);
     L->total_bytes = o;
@@ -104,8 +105,8 @@ inline void image_layout(int W, int H, c3dgs_image_layout* L)
 // ---------------------------------------------------------------- kernel launchers (one per .hip file)
 struct GeomPtrs {
     float4* splat; float* depths; uint32_t* tiles_touched; uint32_t* depth_keys; uint32_t* ids; uint32_t* depth_keys_sorted;
-    uint32_t* depth_order; uint32_t* sorted_offsets; uint32_t* inst_offset; uint16_t* rects;
-    uint8_t* clamped; uint32_t* block_base; void* scan_temp; size_t scan_temp_bytes;
+    uint32_t* depth_order; uint2* sorted_offsets; uint32_t* inst_offset; uint16_t* rects;
+    uint8_t* clamped; uint32_t* block_base; uint32_t* depth_base; void* scan_temp; size_t scan_temp_bytes;
 };
 struct BinPtrs {
     uint16_t* keys_unsorted; uint32_t* values_unsorted; uint16_t* keys_sorted; uint32_t* point_list;
@@ -119,8 +120,9 @@ inline GeomPtrs geom_ptrs(void* base, int P)
     char* b = (char*)base;
     return { (float4*)(b + L.splat), (float*)(b + L.depths), (uint32_t*)(b + L.tiles_touched), (uint32_t*)(b + L.depth_keys),
              (uint32_t*)(b + L.ids), (uint32_t*)(b + L.depth_keys_sorted), (uint32_t*)(b + L.depth_order),
-             (uint32_t*)(b + L.sorted_offsets), (uint32_t*)(b + L.inst_offset), (uint16_t*)(b + L.rects),
-             (uint8_t*)(b + L.clamped), (uint32_t*)(b + L.block_base), (void*)(b + L.scan_temp), L.scan_temp_bytes };
+             (uint2*)(b + L.sorted_offsets), (uint32_t*)(b + L.inst_offset), (uint16_t*)(b + L.rects),
+             (uint8_t*)(b + L.clamped), (uint32_t*)(b + L.block_base), (uint32_t*)(b + L.depth_base), (void*)(b + L.scan_temp),
+             L.scan_temp_bytes };
 }
 inline BinPtrs bin_ptrs(void* base, int R, int W, int H)
 {
@@ -139,13 +141,12 @@ inline ImgPtrs img_ptrs(void* base, int W, int H)
 // preprocess.hip
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, hipStream_t s);
+void launch_depth_order_scan(int P, const GeomPtrs& g, hipStream_t s);   // block totals of tiles_sorted -> depth_base[]
 void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, hipStream_t s);
 void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, hipStream_t s);
 // binning.hip
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
-                          uint32_t* vout, int P, hipStream_t s);
-hipError_t run_scan_in_order(void* temp, size_t temp_bytes, const uint32_t* order, const uint32_t* tiles_touched,
-                             uint32_t* out, int P, hipStream_t s);
+                          uint32_t* vout, int P, const uint2* rects, uint2* rects_sorted, hipStream_t s);
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin,
                          uint32_t* vout, int R, int end_bit, hipStream_t s);
 // radix_sort.hip (hand-written onesweep; C3DGS_SORT_ROCPRIM=1 selects the rocPRIM path of binning.hip instead)
@@ -153,7 +154,7 @@ bool onesweep_enabled();
 size_t onesweep_depth_temp_bytes(int P);
 size_t onesweep_tile_temp_bytes(int R, int end_bit);
 hipError_t onesweep_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
-                               int P, hipStream_t s);
+                               int P, const uint2* gather_src, uint2* gather_dst, hipStream_t s);
 hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin, uint32_t* vout,
                               int R, int end_bit, hipStream_t s);
 // render.hip

@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
     const uint32_t my_incl = woff + incl;
     if (t == 255) a.block_total[blockIdx.x] = my_incl;
     if (!in_range) return;
+    if (!alive) *reinterpret_cast<uint2*>(a.rects + 4 * (size_t)i) = make_uint2(0u, 0u);   // zero tiles for the pair emission
     if (alive) {
         float4* rec = a.splat + 3 * (size_t)i;
         rec[0] = rec0;
@@ -271,26 +272,52 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
 // contiguous output range; its threads walk that range (coalesced 2-byte / 4-byte stores) and find the owning
 // Gaussian of each output by binary search over the 256 scan values in LDS. A thread-per-Gaussian loop (the
 // reference's shape) strands 63 lanes behind the one big splat and scatters its stores.
-__global__ void __launch_bounds__(256)
-duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
-                           const uint32_t* __restrict__ sorted_offsets, const uint16_t* __restrict__ rects,
-                           uint16_t* __restrict__ keys,
-                           uint32_t* __restrict__ values, int grid_x)
+// tiles covered by a packed tile rectangle {x0 | y0 << 16, x1 | y1 << 16} (zero for culled Gaussians)
+__device__ __forceinline__ uint32_t rect_tiles(const uint2 rc)
 {
-    __shared__ uint32_t s_end[256];      // inclusive scan value of each of the block's Gaussians
+    return (uint32_t)(((int)(rc.y & 0xffff) - (int)(rc.x & 0xffff)) * ((int)(rc.y >> 16) - (int)(rc.x >> 16)));
+}
+
+__global__ void __launch_bounds__(256)
+block_totals_kernel(int n, const uint2* __restrict__ rects_sorted, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t x = i < n ? rect_tiles(rects_sorted[i]) : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) totals[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ void __launch_bounds__(256)
+duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint2* __restrict__ rects_sorted,
+                           const uint32_t* __restrict__ depth_base, uint16_t* __restrict__ keys, uint32_t* __restrict__ values,
+                           int grid_x)
+{
+    __shared__ uint32_t s_end[256];      // inclusive emission offset of each of the block's Gaussians
     __shared__ uint32_t s_id[256];
     __shared__ uint2 s_rect[256];
-    const int t = threadIdx.x;
+    __shared__ uint32_t s_wsum[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int k0 = blockIdx.x * 256, k = k0 + t;
-    const uint32_t out_begin = (k0 == 0) ? 0u : sorted_offsets[k0 - 1];
-    uint32_t my_end = out_begin;
-    if (k < P) {
-        const uint32_t i = order[k];
-        my_end = sorted_offsets[k];
-        s_id[t] = i;
-        s_rect[t] = *reinterpret_cast<const uint2*>(rects + 4 * (size_t)i);   // the only gather by id (culled: unused)
+    const uint32_t out_begin = depth_base[blockIdx.x];
+    uint32_t incl = 0;
+    if (k < P) {                              // everything the emission needs arrives coalesced, in depth order
+        const uint2 rc = rects_sorted[k];
+        incl = rect_tiles(rc);
+        s_id[t] = order[k];
+        s_rect[t] = rc;
     }
-    s_end[t] = my_end;
+    // depth-order scan inside the workgroup (the workgroup bases come from scan_blocks_kernel)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = out_begin;
+    for (int w = 0; w < wave; w++) woff += s_wsum[w];
+    s_end[t] = woff + incl;
     __syncthreads();
     const int nk = min(256, P - k0);
     const uint32_t out_end = s_end[nk - 1];
@@ -310,11 +337,20 @@ duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint
     }
 }
 
+// depth-order scan of tiles_touched, second level: totals of the 256-Gaussian groups of the depth order -> depth_base[]
+void launch_depth_order_scan(int P, const GeomPtrs& g, hipStream_t s)
+{
+    if (P <= 0) return;
+    const int nb = (P + 255) / 256;
+    block_totals_kernel<<<nb, 256, 0, s>>>(P, g.sorted_offsets, g.depth_base);
+    scan_blocks_kernel<<<1, 1024, 0, s>>>(nb, g.depth_base);
+}
+
 void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, hipStream_t s)
 {
     if (P <= 0) return;
-    duplicate_with_keys_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.depth_order, g.tiles_touched, g.sorted_offsets, g.rects,
-                                                               b.keys_unsorted, b.values_unsorted, grid_x);
+    duplicate_with_keys_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.depth_order, g.sorted_offsets, g.depth_base, b.keys_unsorted,
+                                                               b.values_unsorted, grid_x);
 }
 
 // ---- K8: reference rasterizer_impl.cu:116-138 (ranges pre-zeroed by the caller, :308)

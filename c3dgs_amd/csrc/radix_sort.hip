@@ -101,7 +101,8 @@ __device__ __forceinline__ void os_store(uint32_t* p, uint32_t v) { __hip_atomic
 template <class K, int BITS>
 __global__ void __launch_bounds__(OsShape<K>::BLOCK)
 os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout,
-               uint32_t n, int shift, const uint32_t* __restrict__ hist, uint32_t* __restrict__ status, uint32_t* __restrict__ ticket)
+               uint32_t n, int shift, const uint32_t* __restrict__ hist, uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
+               const uint2* __restrict__ gather_src, uint2* __restrict__ gather_dst)
 {
     constexpr uint32_t MASK = (1u << BITS) - 1;
     constexpr int OS_BLOCK = OsShape<K>::BLOCK, OS_IPT = OsShape<K>::IPT, OS_WAVES = OS_BLOCK / 64;
@@ -218,20 +219,22 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
             const uint32_t d = ((uint32_t)kk >> shift) & MASK;
             const uint32_t g = (uint32_t)(s_gbase[d] + (int32_t)p);
             kout[g] = kk;
-            vout[g] = s_vals[p];
+            const uint32_t vv = s_vals[p];
+            vout[g] = vv;
+            if (gather_src) gather_dst[g] = gather_src[vv];     // last pass of the depth sort: per-Gaussian data in sorted order
         }
     }
 }
 
 template <class K>
 static void os_launch_pass(int bits, unsigned blocks, hipStream_t s, const K* ki, K* ko, const uint32_t* vi, uint32_t* vo, uint32_t n,
-                           int shift, const uint32_t* hist, uint32_t* status, uint32_t* ticket)
+                           int shift, const uint32_t* hist, uint32_t* status, uint32_t* ticket, const uint2* gsrc, uint2* gdst)
 {
-#define C3DGS_OS_CASE(B) case B: os_pass_kernel<K, B><<<blocks, OsShape<K>::BLOCK, 0, s>>>(ki, ko, vi, vo, n, shift, hist, status, ticket); break
+#define C3DGS_OS_CASE(B) case B: os_pass_kernel<K, B><<<blocks, OsShape<K>::BLOCK, 0, s>>>(ki, ko, vi, vo, n, shift, hist, status, ticket, gsrc, gdst); break
     switch (bits) {
         C3DGS_OS_CASE(1); C3DGS_OS_CASE(2); C3DGS_OS_CASE(3); C3DGS_OS_CASE(4);
         C3DGS_OS_CASE(5); C3DGS_OS_CASE(6); C3DGS_OS_CASE(7);
-        default: os_pass_kernel<K, 8><<<blocks, OsShape<K>::BLOCK, 0, s>>>(ki, ko, vi, vo, n, shift, hist, status, ticket); break;
+        default: os_pass_kernel<K, 8><<<blocks, OsShape<K>::BLOCK, 0, s>>>(ki, ko, vi, vo, n, shift, hist, status, ticket, gsrc, gdst); break;
     }
 #undef C3DGS_OS_CASE
 }
@@ -249,7 +252,7 @@ static size_t os_temp_bytes(size_t n, int total_bits)
 
 template <class K>
 static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, size_t n,
-                          int total_bits, hipStream_t s)
+                          int total_bits, hipStream_t s, const uint2* gather_src = nullptr, uint2* gather_dst = nullptr)
 {
     if (n == 0) return hipSuccess;
     if (n >= ((size_t)1 << 30) || os_temp_bytes<K>(n, total_bits) > temp_bytes) return hipErrorInvalidValue;
@@ -274,8 +277,9 @@ static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, 
         const uint32_t* vi = p == 0 ? vin : tv[(p - 1) & 1];
         K* ko = p == plan.passes - 1 ? kout : tk[p & 1];
         uint32_t* vo = p == plan.passes - 1 ? vout : tv[p & 1];
+        const bool last = p == plan.passes - 1;
         os_launch_pass<K>(plan.bits[p], (unsigned)blocks, s, ki, ko, vi, vo, (uint32_t)n, shift, hist + (size_t)p * OS_RADIX,
-                          status + (size_t)p * blocks * OS_RADIX, ticket + p);
+                          status + (size_t)p * blocks * OS_RADIX, ticket + p, last ? gather_src : nullptr, last ? gather_dst : nullptr);
         shift += plan.bits[p];
     }
     return hipGetLastError();
@@ -289,9 +293,9 @@ bool onesweep_enabled()
 size_t onesweep_depth_temp_bytes(int P) { return os_temp_bytes<uint32_t>((size_t)(P > 0 ? P : 1), 32); }
 size_t onesweep_tile_temp_bytes(int R, int end_bit) { return os_temp_bytes<uint16_t>((size_t)(R > 0 ? R : 1), end_bit); }
 hipError_t onesweep_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
-                               int P, hipStream_t s)
+                               int P, const uint2* gather_src, uint2* gather_dst, hipStream_t s)
 {
-    return os_sort<uint32_t>(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 32, s);
+    return os_sort<uint32_t>(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 32, s, gather_src, gather_dst);
 }
 hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin, uint32_t* vout,
                               int R, int end_bit, hipStream_t s)
