@@ -144,6 +144,7 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
       C3DGS_HIP_TRY(run_depth_sort(g.scan_temp, g.scan_temp_bytes, g.depth_keys, g.depth_keys_sorted, g.ids, g.depth_order, P,
                                    reinterpret_cast<const uint2*>(g.rects), g.sorted_offsets, s)); }
     C3DGS_STAGE("depth_sort", p.debug, s);
+    if (p.debug && onesweep_timed_out(g.scan_temp, (size_t)P, 32, s)) return fail(C3DGS_E_HIP, "depth sort: look-back timed out");
     { StageTimer t_(ST_SCAN, s); launch_depth_order_scan(P, g, s); }                 // K3, in depth order (two-level)
     C3DGS_STAGE("scan", p.debug, s);
     C3DGS_HIP_TRY(hipEventSynchronize(hr.ev));
@@ -165,6 +166,7 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
           C3DGS_HIP_TRY(run_tile_sort(b.sort_temp, b.sort_temp_bytes, b.keys_unsorted, b.keys_sorted, b.values_unsorted,
                                       b.point_list, R, end_bit, s)); }               // K6, binning stage 2
         C3DGS_STAGE("sort", p.debug, s);
+        if (p.debug && onesweep_timed_out(b.sort_temp, (size_t)R, end_bit, s)) return fail(C3DGS_E_HIP, "tile sort: look-back timed out");
         { StageTimer t_(ST_RANGES, s); launch_identify_ranges(R, b.keys_sorted, img.ranges, s); } // K8
         C3DGS_STAGE("identify_ranges", p.debug, s);
     }

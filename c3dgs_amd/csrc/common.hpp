@@ -151,6 +151,7 @@ hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uin
                          uint32_t* vout, int R, int end_bit, hipStream_t s);
 // radix_sort.hip (hand-written onesweep; C3DGS_SORT_ROCPRIM=1 selects the rocPRIM path of binning.hip instead)
 bool onesweep_enabled();
+int onesweep_timed_out(const void* temp, size_t n, int total_bits, hipStream_t s);   // debug mode only (synchronises)
 size_t onesweep_depth_temp_bytes(int P);
 size_t onesweep_tile_temp_bytes(int R, int end_bit);
 hipError_t onesweep_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,

@@ -30,6 +30,10 @@ constexpr int OS_TILE = 8192, OS_RADIX = 256;
 template <class K> struct OsShape { static constexpr int BLOCK = sizeof(K) == 2 ? 1024 : 512; static constexpr int IPT = OS_TILE / BLOCK; };
 constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_PRE = 2u << 30, OS_CNT_MASK = (1u << 30) - 1;
 constexpr int OS_MAX_PASSES = 4;
+// every look-back spin is bounded (a predecessor's word normally arrives within microseconds); on time-out the pass
+// finishes with wrong offsets and raises word OS_ERR_WORD of the ticket block, which debug mode reads back
+constexpr uint32_t OS_SPIN_LIMIT = 1u << 22;
+constexpr int OS_ERR_WORD = 32;
 
 struct OsPlan { int passes; int bits[OS_MAX_PASSES]; };
 
@@ -178,8 +182,9 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
         else {
             os_store(my, OS_FLAG_AGG | tot);
             for (int64_t b = (int64_t)bid - 1;; b--) {
-                uint32_t s;
-                do { s = os_load(status + (size_t)b * OS_RADIX + tid); } while ((s >> 30) == 0);
+                uint32_t s, spins = 0;
+                do { s = os_load(status + (size_t)b * OS_RADIX + tid); } while ((s >> 30) == 0 && ++spins < OS_SPIN_LIMIT);
+                if ((s >> 30) == 0) { atomicOr(ticket + OS_ERR_WORD, 1u); break; }   // never hang the device: give up, flag it
                 pre += s & OS_CNT_MASK;
                 if (s & OS_FLAG_PRE) break;
             }
@@ -278,11 +283,24 @@ static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, 
         K* ko = p == plan.passes - 1 ? kout : tk[p & 1];
         uint32_t* vo = p == plan.passes - 1 ? vout : tv[p & 1];
         const bool last = p == plan.passes - 1;
+        // ticket + p is this pass's counter; the error word sits at a fixed distance behind the FIRST ticket
         os_launch_pass<K>(plan.bits[p], (unsigned)blocks, s, ki, ko, vi, vo, (uint32_t)n, shift, hist + (size_t)p * OS_RADIX,
                           status + (size_t)p * blocks * OS_RADIX, ticket + p, last ? gather_src : nullptr, last ? gather_dst : nullptr);
         shift += plan.bits[p];
     }
     return hipGetLastError();
+}
+
+// debug helper: did any look-back of the last sort in `temp` time out? (synchronises the stream)
+int onesweep_timed_out(const void* temp, size_t n, int total_bits, hipStream_t s)
+{
+    if (!onesweep_enabled() || n == 0 || n >= ((size_t)1 << 30)) return 0;
+    const OsPlan plan = os_plan(total_bits);
+    const uint32_t* ticket = (const uint32_t*)temp + (size_t)plan.passes * OS_RADIX + (size_t)plan.passes * os_blocks(n) * OS_RADIX;
+    uint32_t w[OS_MAX_PASSES] = { 0, 0, 0, 0 };
+    if (hipMemcpyAsync(w, ticket + OS_ERR_WORD, sizeof(w), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
+    if (hipStreamSynchronize(s) != hipSuccess) return 1;
+    return (w[0] | w[1] | w[2] | w[3]) != 0;
 }
 
 bool onesweep_enabled()
