@@ -289,6 +289,32 @@ int c3dgs_profile_read(c3dgs_stage_time* out, int capacity)
 }
 int c3dgs_abi_version(void) { return C3DGS_ABI_VERSION; }
 
+size_t c3dgs_debug_sort_temp_bytes(int32_t key_bytes, int64_t n, int32_t end_bit)
+{
+    if (n <= 0 || n > 0x3fffffff) return 256;
+    return key_bytes == 2 ? onesweep_tile_temp_bytes((int)n, end_bit) : onesweep_depth_temp_bytes((int)n);
+}
+
+int c3dgs_debug_sort_pairs(int32_t key_bytes, int64_t n, int32_t end_bit, const void* keys_in, void* keys_out,
+                           const uint32_t* values_in, uint32_t* values_out, void* temp, size_t temp_bytes, void* stream)
+{
+    if ((key_bytes != 2 && key_bytes != 4) || n < 0 || n > 0x3fffffff || end_bit < 1 || end_bit > 8 * key_bytes)
+        return fail(C3DGS_E_INVALID, "debug_sort_pairs: bad arguments");
+    if (key_bytes == 4 && end_bit != 32) return fail(C3DGS_E_INVALID, "debug_sort_pairs: 4-byte keys are sorted on all 32 bits");
+    if (n == 0) return C3DGS_OK;
+    if (!keys_in || !keys_out || !values_in || !values_out || !temp) return fail(C3DGS_E_INVALID, "debug_sort_pairs: NULL buffer");
+    hipStream_t s = (hipStream_t)stream;
+    if (key_bytes == 2)
+        C3DGS_HIP_TRY(onesweep_tile_sort(temp, temp_bytes, (const uint16_t*)keys_in, (uint16_t*)keys_out, values_in, values_out, (int)n,
+                                         end_bit, s));
+    else
+        C3DGS_HIP_TRY(onesweep_depth_sort(temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)keys_out, values_in, values_out, (int)n,
+                                          nullptr, nullptr, s));
+    C3DGS_STAGE("debug_sort_pairs", 1, s);
+    if (onesweep_timed_out(temp, (size_t)n, key_bytes == 2 ? end_bit : 32, s)) return fail(C3DGS_E_HIP, "debug_sort_pairs: look-back timed out");
+    return C3DGS_OK;
+}
+
 int c3dgs_get_geom_layout(int32_t P, c3dgs_geom_layout* out)
 {
     if (!out || P < 0) return fail(C3DGS_E_INVALID, "bad arguments");

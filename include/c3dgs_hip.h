@@ -286,6 +286,12 @@ typedef struct c3dgs_image_layout {   /* byte offsets into the image buffer     
     size_t tile_used;  /* uint32[T] max n_contrib over the tile's pixels                   */
 } c3dgs_image_layout;
 
+/* tests only: the binning stage's stable LSD radix sort (radix_sort.hip) on caller-provided pairs. key_bytes = 2 (tile
+ * keys) or 4 (depth keys); bits [0, end_bit) are sorted; ties keep input order. temp >= c3dgs_debug_sort_temp_bytes(). */
+size_t c3dgs_debug_sort_temp_bytes(int32_t key_bytes, int64_t n, int32_t end_bit);
+int c3dgs_debug_sort_pairs(int32_t key_bytes, int64_t n, int32_t end_bit, const void* keys_in, void* keys_out,
+                           const uint32_t* values_in, uint32_t* values_out, void* temp, size_t temp_bytes, void* stream);
+
 int c3dgs_get_geom_layout(int32_t P, c3dgs_geom_layout* out);
 int c3dgs_get_binning_layout(int32_t R, int32_t W, int32_t H, c3dgs_binning_layout* out);
 int c3dgs_get_image_layout(int32_t W, int32_t H, c3dgs_image_layout* out);

@@ -1,0 +1,61 @@
+"""-m gpu: the hand-written stable onesweep radix sort of the binning stage (csrc/radix_sort.hip) against torch's stable
+sort: ragged sizes around the 8192-item tile, every digit split the tile sort can take, heavy ties, both key widths."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _sort(keys, values, end_bit):
+    from c3dgs_amd import _lib
+    L = _lib.lib()
+    kb = keys.element_size()
+    n = keys.numel()
+    tb = int(L.c3dgs_debug_sort_temp_bytes(kb, n, end_bit))
+    temp = torch.empty(max(tb, 256), dtype=torch.uint8, device="cuda")
+    ko, vo = torch.empty_like(keys), torch.empty_like(values)
+    _lib.check(L.c3dgs_debug_sort_pairs(kb, n, end_bit, keys.data_ptr(), ko.data_ptr(), values.data_ptr(), vo.data_ptr(),
+                                        temp.data_ptr(), tb, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return ko, vo
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 8191, 8192, 8193, 16384, 100_003, 1_000_000, 3_000_001])
+def test_tile_key_sort_is_stable_for_ragged_sizes(n):
+    g = torch.Generator(device="cuda").manual_seed(n)
+    for end_bit, hi in ((13, 8160), (7, 100), (16, 65536), (9, 300), (1, 2)):
+        keys = torch.randint(0, min(hi, 1 << end_bit), (n,), device="cuda", generator=g, dtype=torch.int32).to(torch.int16)
+        vals = torch.arange(n, device="cuda", dtype=torch.int32)
+        ko, vo = _sort(keys, vals, end_bit)
+        k32 = keys.to(torch.int32) & 0xffff
+        want = torch.sort(k32, stable=True)
+        assert torch.equal(vo.long(), want.indices), (n, end_bit)
+        assert torch.equal(ko.to(torch.int32) & 0xffff, want.values), (n, end_bit)
+
+
+@pytest.mark.parametrize("n", [1, 511, 8192, 8193, 300_000, 3_000_000])
+def test_depth_key_sort_matches_stable_sort(n):
+    g = torch.Generator(device="cuda").manual_seed(n + 7)
+    depth = torch.rand(n, device="cuda", generator=g) * 10 + 2
+    depth[torch.rand(n, device="cuda", generator=g) < 0.06] = float("nan")          # culled: key 0xFFFFFFFF
+    keys = depth.view(torch.int32).clone()
+    keys[torch.isnan(depth)] = -1
+    keys[::7] = int(keys[0])                                                       # heavy ties
+    vals = torch.arange(n, device="cuda", dtype=torch.int32)
+    ko, vo = _sort(keys, vals, 32)
+    ku = keys.to(torch.int64) & 0xffffffff
+    want = torch.sort(ku, stable=True)
+    assert torch.equal(vo.long(), want.indices)
+    assert torch.equal(ko.to(torch.int64) & 0xffffffff, want.values)
+
+
+def test_sort_of_already_sorted_and_constant_keys():
+    n = 50_000
+    vals = torch.arange(n, device="cuda", dtype=torch.int32)
+    const = torch.full((n,), 4321, device="cuda", dtype=torch.int16)
+    ko, vo = _sort(const, vals, 13)
+    assert torch.equal(vo, vals) and torch.equal(ko, const)
+    asc = (torch.arange(n, device="cuda") * 8160 // n).to(torch.int16)
+    ko, vo = _sort(asc, vals, 13)
+    assert torch.equal(vo, vals) and torch.equal(ko, asc)
