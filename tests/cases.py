@@ -31,6 +31,11 @@ def make_case(name, P=4000, W=200, H=136, focal=125.0, seed=7, scale_median=0.03
     sc = synth.scene(P, W, H, focal, seed=seed, sh_degree=3, scale_median=scale_median, **kw)
     if name == "all_behind":
         sc["means3D"][:, 2] = -sc["means3D"][:, 2].abs() - 1.0
+    if name == "wide_depth":     # depths over five decades (0.05 .. 6000): every digit of the depth sort keys is exercised
+        g = torch.Generator().manual_seed(11)
+        z = torch.exp(torch.rand(P, generator=g) * (np.log(6000.0) - np.log(0.05)) + np.log(0.05)).float()
+        sc["means3D"] = sc["means3D"] * (z / sc["means3D"][:, 2])[:, None]
+        sc["scales"] = sc["scales"] * (z / 7.0)[:, None]
     if name == "frustum_edge":   # exercise the 1.3*tan_fov clamp of computeCov2D
         sc["means3D"][:, 0] *= 1.6
         sc["scales"] *= 3.0
@@ -87,4 +92,4 @@ def oracle_forward(inp, cam):
 
 FORWARD_CASES = ["tiny", "base", "odd_size", "behind", "all_behind", "empty", "deg0", "deg1", "deg2", "no_clamp",
                  "clamp_hits", "black_bg", "scale_mod", "colors_precomp", "cov_precomp", "frustum_edge", "indexed",
-                 "indexed_deg1", "indexed_scale_mod"]
+                 "indexed_deg1", "indexed_scale_mod", "wide_depth"]
