@@ -34,6 +34,9 @@ size_t sort_temp_bytes(int R, int end_bit)
                                     (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)R, 0u, (unsigned)end_bit);
     const size_t os = onesweep_tile_temp_bytes(R, end_bit);
     if (os > bytes) bytes = os;
+    // after the sort the region is reused for the R quadrant-mask bytes
+    const size_t reuse = align_up((size_t)(R > 0 ? R : 1));
+    if (reuse > bytes) bytes = reuse;
     return bytes < 256 ? 256 : bytes;
 }
 

@@ -223,7 +223,7 @@ static int backward_impl(const c3dgs_raster_params* pp, bool indexed, const int3
         const BinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), R, W, H);
         { StageTimer t_(ST_RENDER_BWD, s);
           launch_render_backward(W, H, img, b.point_list, g.splat, g.block_base, p.background, dL_dout_color, partials, touched,
-                                 (const uint8_t*)b.sort_temp, s); } // K10
+                                 (const uint8_t*)b.sort_temp, (uint32_t*)(touched + align_up((size_t)(R > 0 ? R : 1))), s); } // K10
         C3DGS_STAGE("render_backward", p.debug, s);
     }
     { StageTimer t_(ST_BWD_PREPROCESS, s); launch_backward_preprocess(p, radii, g, partials, touched, *grads, s); } // K11 + K12(i)
@@ -337,7 +337,8 @@ size_t c3dgs_backward_workspace_bytes(int32_t P, int32_t R)
 {
     (void)P;
     const size_t r = (size_t)(R > 0 ? R : 1);
-    return align_up(r * PARTIAL_FLOATS * sizeof(float)) + align_up(r);   // partial sums + 1-byte written flags
+    // partial sums + 1-byte written flags + the backward's tile schedule (at most 65536 tiles)
+    return align_up(r * PARTIAL_FLOATS * sizeof(float)) + align_up(r) + 65536 * sizeof(uint32_t);
 }
 
 int c3dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

@@ -163,7 +163,7 @@ void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* poi
                            const float* bg, float* out_color, uint8_t* qmask, hipStream_t s);
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                             const uint32_t* block_base, const float* bg, const float* dL_dpix, float* partials,
-                            uint8_t* touched, const uint8_t* qmask, hipStream_t s);
+                            uint8_t* touched, const uint8_t* qmask, uint32_t* tile_order, hipStream_t s);
 // backward_preprocess.hip
 void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* radii, const GeomPtrs& g,
                                 const float* partials, const uint8_t* touched, const c3dgs_raster_grads& gr, hipStream_t s);
