@@ -618,7 +618,12 @@ class GaussianModel:
         ev.record(torch.cuda.current_stream(dev))
 
         def read():
-            ev.synchronize()
+            spins = 0
+            while not ev.query():                 # poll: a blocking wait can cost milliseconds of wake-up on a busy host
+                spins += 1
+                if spins > 2_000_000:
+                    ev.synchronize()
+                    break
             return int(self._count_host[0])
         return visible, rank, read
 

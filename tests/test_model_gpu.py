@@ -305,3 +305,39 @@ def test_save_npz_codes_equal_device_torch_quantize_and_file_round_trips(tmp_pat
     assert sorted(map(tuple, sd2["xyz"].astype(np.float32))) == sorted(map(tuple, sd["xyz"].astype(np.float32)))
     from oracle import oracle as orc
     assert np.array_equal(sd2["xyz"], raw["xyz"].numpy()[orc.morton_order(raw["xyz"].numpy())].astype(np.float16))
+
+
+def test_exp_scaling_model_without_factor_scaling(tmp_path):
+    """use_factor_scaling=False (gaussian_model.py:73-75): scaling_activation = exp, no scaling factor; getters, the
+    non-indexed render and the npz payload go through the stand-alone module / QACT_EXP paths."""
+    from c3dgs_amd.model import GaussianModel, PipelineParams
+    W, H = 320, 200
+    sc = synth.scene(4000, W=W, H=H, focal=300.0, seed=9, scale_median=0.02)
+    op = sc["opacities"].clamp(1e-6, 1 - 1e-6)
+    m = GaussianModel(3, quantization=True, use_factor_scaling=False, device=DEV)
+    m.set_tensors(xyz=sc["means3D"], features_dc=sc["shs"][:, :1], features_rest=sc["shs"][:, 1:], scaling=torch.log(sc["scales"]),
+                  rotation=sc["rotations"], opacity=torch.log(op / (1 - op)))
+    ref_fq = torch.ao.quantization.FakeQuantize(dtype=torch.qint8).to(DEV)
+    want = ref_fq(torch.exp(m._scaling.detach()))
+    got = m.get_scaling
+    assert float(m.scaling_qa.scale) == pytest.approx(float(ref_fq.scale), rel=3e-7)
+    _flip_close(got.detach().cpu().numpy(), want.cpu().numpy(), float(ref_fq.scale), "exp scaling")
+    intr, ev = synth.camera(W, H, 300.0)
+    cam, bg = _Cam(intr, ev), torch.zeros(3, device=DEV)
+    out = m.render(cam, PipelineParams(), bg)
+    assert float(out["render"].sum()) > 0
+    out["render"].sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    path = str(tmp_path / "exp.npz")
+    m.save_npz(path)
+    sd = np.load(path)
+    assert "scaling_factor" not in sd and sd["scaling"].dtype == np.int8
+    code = torch.quantize_per_tensor(torch.exp(m._scaling.detach()), m.scaling_qa.scale, m.scaling_qa.zero_point,
+                                     torch.qint8).int_repr().cpu().numpy()
+    d = sd["scaling"].astype(np.int32) - code
+    assert (d != 0).mean() < 1e-3 and np.abs(d).max() <= 1
+    m2 = GaussianModel(3, quantization=True, use_factor_scaling=False, device=DEV).load_npz(path)
+    assert m2._scaling_factor is None and m2._scaling.shape == m._scaling.shape
+    # log(dequantised exp(s)) is what the reference stores back (scaling_inverse_activation = log)
+    ok = torch.isfinite(m2._scaling)
+    assert ok.float().mean() > 0.99
