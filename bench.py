@@ -215,6 +215,9 @@ def main():
                      "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": dom_bytes,
                      "avg_launch_ms": stage_ms[dom]},
         "stages_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])},
+        # informational: kernels of one step (untimed profiling pass) vs the timed step. A ratio far above 1 means the
+        # GPU sat idle waiting for the host during the timed region (seen once on a heavily loaded box: profiles/README.md)
+        "step_over_kernel_time": (1e3 * elapsed / args.steps) / max(sum(v for k, v in stage_ms.items() if k in raster_names), 1e-9),
         "view_alg_bytes": view_bytes,
         "view_hbm_frac": view_bytes * (args.steps / elapsed) / 1e9 / HBM_PEAK_GBS,
     }
