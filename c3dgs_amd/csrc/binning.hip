@@ -1,4 +1,6 @@
-// binning.hip -- prefix sum and the two radix sorts of the binning stage on rocPRIM (gfx950).
+// binning.hip -- the two sorts of the binning stage: dispatch to the hand-written onesweep (radix_sort.hip, default) or to
+// rocPRIM (C3DGS_SORT_ROCPRIM=1, and beyond 2^30 items), and the scratch sizes both need (gfx950).
+// The two prefix sums (cub::DeviceScan::InclusiveSum in the reference) are two-level scans folded into preprocess.hip.
 //
 // Reference: cub::DeviceScan::InclusiveSum (rasterizer_impl.cu:162,275) and ONE
 // cub::DeviceRadixSort::SortPairs<uint64,uint32> over all R tile instances on bits [0, 32+bit) (:184-187, 301-306):
@@ -18,7 +20,7 @@ namespace c3dgs {
 
 size_t scan_temp_bytes(int P)
 {
-    size_t a = 0, b = 0;
+    size_t a = 0, b = 0;                                          // a: reserved for other users of the region
     (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
                                     (uint32_t*)nullptr, (size_t)P, 0u, 32u);
     size_t m = a > b ? a : b;

@@ -262,7 +262,7 @@ typedef struct c3dgs_geom_layout {   /* byte offsets into the geometry buffer fo
     size_t inst_offset;    /* uint32[P] inclusive scan of tiles_touched in ID order WITHIN each 256-Gaussian group; + block_base[i>>8] = backward slot end of i */
     size_t rects;          /* uint16[4*P]: xmin, ymin, xmax, ymax (tile units)             */
     size_t clamped;        /* uint8[P] bit c set = channel c was clamped                   */
-    size_t scan_temp;      /* rocPRIM scan / depth-sort temporary storage                  */
+    size_t scan_temp;      /* depth-sort temporary storage (control words + ping/pong buffers) */
     size_t scan_temp_bytes;
     size_t block_base;     /* uint32[ceil(P/256)+1] instances before each 256-Gaussian group; last = num_rendered */
     size_t depth_base;     /* uint32[ceil(P/256)+1] the same for groups of the DEPTH order (where the pairs are emitted) */
