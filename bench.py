@@ -317,8 +317,30 @@ def bench_qat_model(c3dgs_amd, _lib, dev, ix_cpu, intr, evd, W, H, steps, barrie
                         scale_factors=sfac[vis], rotations=rotations, cov3D_precomp=None, extrinsic_vector=evd)
         lossm.l1_ssim_loss(color, gt, 0.2).backward()
 
+    # the complete QAT iteration of finetune.py:29-66 incl. optimizer.step(): per-group learning rates of
+    # scene/gaussian_model.py:296-308, eps 1e-15
+    from c3dgs_amd import optim as optm
+    lrs = (0.00016, 0.0025, 0.0025 / 20.0, 0.005, 0.005, 0.001, 0.05)
+
+    def groups(ps):
+        return [{"params": [p], "lr": lr} for p, lr in zip(ps, lrs)]
+    opt_fused = optm.Adam(groups(m.parameters()), lr=0.0, eps=1e-15)
+    opt_torch = torch.optim.Adam(groups([leaves[k] for k in ("xyz", "features_dc", "features_rest", "scaling", "scaling_factor",
+                                                               "rotation", "opacity")]), lr=0.0, eps=1e-15)
+
+    def fused_iteration():
+        lossm.l1_ssim_loss(m.render(cam, pipe, bg)["render"], gt, 0.2).backward()
+        opt_fused.step()
+        opt_fused.zero_grad(set_to_none=True)
+
+    def torch_iteration():
+        torch_glue_step()
+        opt_torch.step()
+        opt_torch.zero_grad(set_to_none=True)
+
     res = {"metric": "views/s of a whole QAT view from raw parameters (getters + raster + L1/SSIM loss + backward)"}
-    for name, fn in (("fused_glue", fused_step), ("torch_glue", torch_glue_step)):
+    for name, fn in (("fused_glue", fused_step), ("torch_glue", torch_glue_step), ("iteration_fused_glue_fused_adam", fused_iteration),
+                     ("iteration_torch_glue_torch_adam", torch_iteration)):
         for _ in range(4):
             fn()
         barrier()
@@ -336,6 +358,14 @@ def bench_qat_model(c3dgs_amd, _lib, dev, ix_cpu, intr, evd, W, H, steps, barrie
     st = _lib.profile_read()
     _lib.profile_enable(False)
     res["glue_stages_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in st.items() if k.startswith("qat_")}
+    _lib.profile_enable(True, only="adam_step")
+    _lib.profile_read()
+    for _ in range(5):
+        fused_iteration()
+    torch.cuda.synchronize()
+    st = _lib.profile_read()
+    _lib.profile_enable(False)
+    res["adam_step_ms"] = round(st["adam_step"][0] / max(st["adam_step"][1], 1), 4) if "adam_step" in st else None
     res["glue_only_ms"] = {"fused": round(sum(res["glue_stages_ms"].values()), 4)}
     return res
 

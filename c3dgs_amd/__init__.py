@@ -8,6 +8,7 @@ Drop-in for the reference's two native extensions and the Python directly around
     c3dgs_amd.sensitivity <->  compress.py:calc_importance_experimental (camera-sharded)
     c3dgs_amd.encode      <->  GaussianModel._sort_morton / mortonEncode
     c3dgs_amd.model       <->  GaussianModel getters + FakeQuantize modules + render() glue (scene/gaussian_model.py)
+    c3dgs_amd.optim       <->  the torch.optim.Adam step of the QAT loop (finetune.py:65-66), one fused launch
 
 The numeric work runs in c3dgs_amd/libc3dgs_hip.so (include/c3dgs_hip.h); build it with
 `python -m c3dgs_amd.build`.  There is no CPU fallback.
@@ -15,7 +16,7 @@ The numeric work runs in c3dgs_amd/libc3dgs_hip.so (include/c3dgs_hip.h); build 
 import sys
 import types
 
-from . import encode, loss, model, rasterizer, sensitivity, vq  # noqa: F401
+from . import encode, loss, model, optim, rasterizer, sensitivity, vq  # noqa: F401
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, GaussianRasterizerIndexed,  # noqa: F401
                          getProjectionMatrix, mat_to_quat, quat_to_mat, rasterize_gaussians,
                          rasterize_gaussians_indexed, rasterize_gaussians_indexed_camera)

@@ -60,6 +60,11 @@ class QatParams(C.Structure):
                 ("half_xyz", C.c_int32), ("averaging_constant", C.c_float)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64),
+                ("step_size", C.c_float), ("bias_correction2_sqrt", C.c_float)]
+
+
 _vp = C.c_void_p
 # name -> (restype, argtypes); every symbol include/c3dgs_hip.h declares
 PROTOTYPES = {
@@ -82,6 +87,7 @@ PROTOTYPES = {
                                  C.c_int32, C.c_void_p]),
     "c3dgs_morton_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "c3dgs_morton_order": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c3dgs_adam_step": (C.c_int, [C.c_int32, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _vp]),
     "c3dgs_extract_rot_scale": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "c3dgs_l1_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),

@@ -30,6 +30,7 @@ SOURCES = {
     "vq.hip": [],
     "loss.hip": [],
     "encode.hip": [],
+    "adam.hip": ["-ffp-contract=off"],
     "qat.hip": ["-ffp-contract=off"],
 }
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gsmath.hpp"),

@@ -15,12 +15,12 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 // synchronises until c3dgs_profile_read().
 enum Stage { ST_MARK_VISIBLE, ST_PREPROCESS, ST_DEPTH_SORT, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_ZERO_PARTIALS,
              ST_RENDER_BWD, ST_BWD_PREPROCESS, ST_WDIST, ST_VQ_ACC, ST_VQ_APPLY, ST_LOSS_FWD, ST_LOSS_BWD,
-             ST_QAT_OBSERVE, ST_QAT_CODEBOOKS, ST_QAT_VISIBLE, ST_QAT_POINTS, ST_QAT_POINTS_BWD, ST_QAT_CODEBOOKS_BWD, ST_COUNT };
+             ST_QAT_OBSERVE, ST_QAT_CODEBOOKS, ST_QAT_VISIBLE, ST_QAT_POINTS, ST_QAT_POINTS_BWD, ST_QAT_CODEBOOKS_BWD, ST_ADAM, ST_COUNT };
 static const char* kStageNames[ST_COUNT] = { "mark_visible", "preprocess", "depth_sort", "scan", "duplicate_with_keys", "sort",
                                              "identify_ranges", "render_forward", "zero_partials", "render_backward",
                                              "backward_preprocess", "weighted_distance", "vq_accumulate", "vq_apply", "l1_ssim_forward",
                                              "l1_ssim_backward", "qat_observe", "qat_codebooks", "qat_visible", "qat_points",
-                                             "qat_points_backward", "qat_codebooks_backward" };
+                                             "qat_points_backward", "qat_codebooks_backward", "adam_step" };
 struct ProfRec { int stage; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -438,6 +438,19 @@ int c3dgs_morton_order(int32_t P, const float* xyz, int64_t* codes, int64_t* ord
     if (!xyz || !codes || !order || !workspace) return fail(C3DGS_E_INVALID, "morton_order: bad arguments");
     if (run_morton_order(P, xyz, codes, order, workspace, (hipStream_t)stream)) return fail(C3DGS_E_HIP, "morton_order failed");
     C3DGS_STAGE("morton_order", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_adam_step(int32_t n_tensors, const c3dgs_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream)
+{
+    if (n_tensors < 0 || n_tensors > C3DGS_ADAM_MAX_TENSORS) return fail(C3DGS_E_INVALID, "adam_step: between 0 and 16 tensors per call");
+    if (n_tensors == 0) return C3DGS_OK;
+    if (!tensors) return fail(C3DGS_E_INVALID, "adam_step: tensors is NULL");
+    for (int k = 0; k < n_tensors; k++)
+        if (tensors[k].n > 0 && (!tensors[k].param || !tensors[k].grad || !tensors[k].exp_avg || !tensors[k].exp_avg_sq))
+            return fail(C3DGS_E_INVALID, "adam_step: NULL tensor pointer");
+    { StageTimer t_(ST_ADAM, (hipStream_t)stream); launch_adam(n_tensors, tensors, beta1, beta2, eps, (hipStream_t)stream); }
+    C3DGS_STAGE("adam_step", 0, (hipStream_t)stream);
     return C3DGS_OK;
 }
 

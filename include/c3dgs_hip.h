@@ -162,6 +162,22 @@ size_t c3dgs_morton_workspace_bytes(int32_t P);
 int c3dgs_morton_order(int32_t P, const float* xyz /*[P,3]*/, int64_t* codes /*[P]*/, int64_t* order /*[P]*/,
                        void* workspace, void* stream);
 
+/* ---- fused Adam step (the optimizer.step() that closes the QAT inner loop, finetune.py:65-66; optimizer set-up
+ * scene/gaussian_model.py:296-308: torch.optim.Adam(param groups, lr=0.0, eps=1e-15), no weight decay, no amsgrad).
+ * ONE launch updates up to C3DGS_ADAM_MAX_TENSORS tensors with torch's _single_tensor_adam arithmetic; the caller passes
+ * per tensor step_size = lr / (1 - beta1^t) and bias_correction2_sqrt = sqrt(1 - beta2^t) (computed in double, as torch does). */
+#define C3DGS_ADAM_MAX_TENSORS 16
+typedef struct c3dgs_adam_tensor {
+    float* param;            /* [n] updated in place */
+    const float* grad;       /* [n]                  */
+    float* exp_avg;          /* [n] first moment     */
+    float* exp_avg_sq;       /* [n] second moment    */
+    int64_t n;
+    float step_size;
+    float bias_correction2_sqrt;
+} c3dgs_adam_tensor;
+int c3dgs_adam_step(int32_t n_tensors, const c3dgs_adam_tensor* tensors /*host*/, double beta1, double beta2, double eps, void* stream);
+
 /* ---- extract_rot_scale(to_full_cov(cov)) (utils/splats.py:7-35; compress_covariance, compression/vq.py:186):
  * cov6[n,6] = upper triangle (xx,xy,xz,yy,yz,zz) -> rot[n,4] unit quaternion (r,x,y,z) of the eigenvector frame with
  * determinant +1, scale[n,3] = sqrt of the ascending eigenvalues of cov + 1e-8 I (NaN -> 1e-6). */
