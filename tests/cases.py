@@ -27,8 +27,29 @@ def make_case(name, P=4000, W=200, H=136, focal=125.0, seed=7, scale_median=0.03
         kw["behind_fraction"] = 0.3
     if name.startswith("deg"):
         deg = int(name[3])
-    cam, intr, ev = _cam(W, H, focal)
+    if name == "deep_tile":      # thousands of faint splats stacked over four tiles: many staging rounds per tile
+        P, W, H, focal, scale_median = 5000, 32, 32, 30.0, 0.2
+        kw = dict(zmin=3, zmax=9)
+    if name == "huge_splats":    # every splat's rectangle is clipped by the screen: R = P x (all tiles)
+        P, W, H, focal, scale_median = 300, 150, 100, 90.0, 6.0
+    if name == "one_tile":       # a 1 x 1 tile grid, narrower than one wave's pixel block
+        P, W, H, focal, scale_median = 200, 9, 5, 8.0, 0.3
+        kw = dict(zmin=2, zmax=6)
+    if name == "p257":           # one Gaussian past a 256-block of the two-level scans
+        P = 257
+    if name == "p8193":          # one key past an 8192-item tile of the sorts
+        P = 8193
+    ev = (0.05, -0.03, 0.02, 0.99, 0.1, -0.05, 0.2)
+    if name == "equal_depth":    # identity camera + one z: all depth keys tie -> the stable sort must keep id order
+        ev = (0, 0, 0, 1, 0, 0, 0)
+    cam, intr, ev = _cam(W, H, focal, ev)
     sc = synth.scene(P, W, H, focal, seed=seed, sh_degree=3, scale_median=scale_median, **kw)
+    if name == "deep_tile":
+        sc["opacities"] = sc["opacities"] * 0.02
+    if name == "equal_depth":
+        sc["means3D"][:, :2] *= (5.0 / sc["means3D"][:, 2])[:, None]
+        sc["means3D"][:, 2] = 5.0
+        sc["means3D"][::3, 2] = 5.5
     if name == "all_behind":
         sc["means3D"][:, 2] = -sc["means3D"][:, 2].abs() - 1.0
     if name == "wide_depth":     # depths over five decades (0.05 .. 6000): every digit of the depth sort keys is exercised
@@ -92,4 +113,5 @@ def oracle_forward(inp, cam):
 
 FORWARD_CASES = ["tiny", "base", "odd_size", "behind", "all_behind", "empty", "deg0", "deg1", "deg2", "no_clamp",
                  "clamp_hits", "black_bg", "scale_mod", "colors_precomp", "cov_precomp", "frustum_edge", "indexed",
-                 "indexed_deg1", "indexed_scale_mod", "wide_depth"]
+                 "indexed_deg1", "indexed_scale_mod", "wide_depth", "deep_tile", "huge_splats", "one_tile", "p257", "p8193",
+                 "equal_depth"]
