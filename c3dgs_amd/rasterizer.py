@@ -137,8 +137,16 @@ class _Scratch:
         self._cbs[name] = cb
         return cb
 
-    def get(self, name):
-        t = self.bufs.get(name)
+    def release(self):
+        """-> the buffers; drops the callbacks. Must be called once the library call has returned: each callback
+        closes over `self`, so the object sits in a reference cycle and would otherwise keep its buffers (hundreds of
+        MB per call) alive until the cyclic garbage collector runs -- the caching allocator then has to hipMalloc new
+        blocks every few calls."""
+        bufs, self.bufs, self._cbs = self.bufs, {}, {}
+        return bufs
+
+    def _or_empty(self, bufs, name):
+        t = bufs.get(name)
         return t if t is not None else torch.empty(0, dtype=torch.uint8, device=self.device)
 
 
@@ -225,8 +233,10 @@ def _forward(indexed, background, means3D, colors, opacity, scales, scale_factor
         fn = L.c3dgs_rasterize_gaussians_indexed if indexed else L.c3dgs_rasterize_gaussians
         rc = fn(C.byref(p), scratch.callback("geom"), None, scratch.callback("binning"), None, scratch.callback("img"), None,
                 out_color.data_ptr(), radii.data_ptr() if P > 0 else None, C.byref(num_rendered), _stream(dev))
+    bufs = scratch.release()
     _lib.check(rc)
-    return int(num_rendered.value), out_color, radii, scratch.get("geom"), scratch.get("binning"), scratch.get("img")
+    return (int(num_rendered.value), out_color, radii, scratch._or_empty(bufs, "geom"), scratch._or_empty(bufs, "binning"),
+            scratch._or_empty(bufs, "img"))
 
 
 # Outputs the autograd wrappers do not need (gradients of ABSENT optional inputs) are neither allocated nor written:
@@ -290,6 +300,7 @@ def _backward(indexed, background, means3D, radii, colors, scales, scale_factors
                 binningBuffer.data_ptr() if binningBuffer.numel() else None,
                 imageBuffer.data_ptr() if imageBuffer.numel() else None, int(R), _ptr(dpix),
                 scratch.callback("ws"), None, C.byref(g), _stream(dev))
+    scratch.release()       # the workspace goes back to the (stream-ordered) caching allocator right away
     _lib.check(rc)
     if indexed:
         if t["scales"] is None:

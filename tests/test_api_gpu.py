@@ -116,3 +116,29 @@ def test_sensitivity_pass_on_gpu(hip, orc):
     want_cg = np.abs(ref["dL_dcov3D"]) * (1.3 ** 2) / npx
     assert gpu_util.rel_inf(imp.cpu().numpy(), want_imp) <= 2e-4
     assert gpu_util.rel_inf(cg.cpu().numpy(), want_cg) <= 2e-4
+
+
+def test_steady_state_makes_no_device_allocations(hip):
+    """Scratch goes back to the caching allocator when a call returns (no reference cycles holding it): after a
+    warm-up, repeated forward+backward calls must not hipMalloc."""
+    import gc
+    from c3dgs_amd import rasterizer as rz
+    inp, cam, indexed = cases.make_case("base")
+    dL = synth.grad_image(cam["W"], cam["H"]).numpy()
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(4):
+            fw = gpu_util.hip_forward(inp, cam, indexed)
+            gpu_util.hip_backward(fw, dL)
+            del fw
+        n0 = torch.cuda.memory_stats()["num_device_alloc"]
+        r0 = torch.cuda.memory_reserved()
+        for _ in range(12):
+            fw = gpu_util.hip_forward(inp, cam, indexed)
+            gpu_util.hip_backward(fw, dL)
+            del fw
+        assert torch.cuda.memory_stats()["num_device_alloc"] == n0
+        assert torch.cuda.memory_reserved() == r0
+    finally:
+        gc.enable()

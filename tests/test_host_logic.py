@@ -104,3 +104,25 @@ def test_batch_draws_equal_reference_stream():
     torch.manual_seed(3)
     d = _BatchDraws(1000, 37, 11, "cpu")
     assert all(torch.equal(a, d.next()) for a in ref)
+
+
+def test_scratch_owner_dies_without_the_cycle_collector():
+    """The resize callbacks close over their owner (a reference cycle); release() must break it, otherwise every
+    call's scratch (hundreds of MB) stays allocated until gc runs and the caching allocator keeps growing."""
+    import gc
+    import weakref
+    gc.disable()
+    try:
+        s = rz._Scratch(torch.device("cpu"))
+        cb = s.callback("geom")
+        assert cb(None, 64) != 0
+        wt = weakref.ref(s.bufs["geom"])
+        bufs = s.release()
+        ws = weakref.ref(s)
+        del s, cb
+        assert ws() is None                      # freed by reference counting alone
+        assert wt() is not None and bufs["geom"].numel() == 64
+        del bufs
+        assert wt() is None
+    finally:
+        gc.enable()

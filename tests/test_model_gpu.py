@@ -341,3 +341,37 @@ def test_exp_scaling_model_without_factor_scaling(tmp_path):
     # log(dequantised exp(s)) is what the reference stores back (scaling_inverse_activation = log)
     ok = torch.isfinite(m2._scaling)
     assert ok.float().mean() > 0.99
+
+
+def test_training_iteration_makes_no_device_allocations_in_steady_state():
+    """render -> fused loss -> backward -> fused Adam: everything a step allocates must return to the caching allocator
+    by reference counting (no cycles through ctypes callbacks / autograd contexts), so a warmed-up loop never hipMallocs."""
+    import gc
+    from c3dgs_amd import loss as closs, optim
+    from c3dgs_amd.model import PipelineParams
+    W, H = 320, 200
+    m = _model(_raw(5, P=8000, W=W, H=H))
+    intr, ev = synth.camera(W, H, 300.0)
+    cam = _Cam(intr, ev)
+    bg = torch.zeros(3, device=DEV)
+    gt = torch.rand(3, H, W, device=DEV)
+    opt = optim.Adam([{"params": [p], "lr": 1e-4} for p in m.parameters()], lr=1e-4)
+
+    def step():
+        out = m.render(cam, PipelineParams(), bg)
+        closs.l1_ssim_loss(out["render"], gt).backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(5):
+            step()
+        n0, r0 = torch.cuda.memory_stats()["num_device_alloc"], torch.cuda.memory_reserved()
+        for _ in range(12):
+            step()
+        assert torch.cuda.memory_stats()["num_device_alloc"] == n0
+        assert torch.cuda.memory_reserved() == r0
+    finally:
+        gc.enable()
