@@ -28,6 +28,7 @@ SOURCES = {
     # SLP packing into v_pk_*_f32 costs register shuffles in the blend loops and keeps DPP adds from fusing
     "render.hip": os.environ.get("C3DGS_RENDER_FLAGS", "-fno-slp-vectorize").split(),
     "vq.hip": [],
+    "draws.hip": [],
     "loss.hip": [],
     "encode.hip": [],
     "adam.hip": ["-ffp-contract=off"],

@@ -137,19 +137,71 @@ class VectorQuantize(nn.Module):
         return self.codebook[idx], idx
 
 
+# torch.get_rng_state() of the CPU generator: at::CPUGeneratorImplStateLegacy = { u64 seed; i32 left; i32 seeded; u64 next;
+# u64 state[624]; normal-distribution cache } + the float-normal cache -- 5056 bytes. _MT_LEFT indexes the int32 view,
+# _MT_NEXT / _MT_STATE the int64 view.
+_MT_WORDS, _MT_LEFT, _MT_NEXT, _MT_STATE, _MT_BYTES = 624, 2, 2, 3, 5056
+_FAST_DRAWS = True      # False: every batch through torch.randint itself (what the tests compare the fast path with)
+
+
 class _BatchDraws:
-    """The batch indices of one Lloyd step. Default: exactly the reference's draw -- `torch.randint(0, N, [chunk])` on the
-    CPU default generator (vq.py:69) -- issued inline: the GPU work of the previous step runs asynchronously underneath,
-    so the host RNG (about 2 ms for 2^18 draws) is the floor of a step either way (a prefetch thread was measured and is
-    slower). device_rng=True draws on the GPU instead: no host work, different numbers."""
+    """The batch indices of one Lloyd step: exactly the reference's draws, `torch.randint(0, N, [chunk])` on the CPU
+    default generator (vq.py:69), i.e. `mt19937() % N` per element. torch's scalar path costs ~2 ns per draw (2 ms for a
+    2^20 batch -- more than the step's kernels), so the generator's stream is continued by the library's block-wise
+    MT19937 (csrc/draws.hip) into a ring of pinned buffers as raw 32-bit words, copied at 4 B/draw, and reduced `% N`
+    on the GPU. The advanced state is written back to the torch generator by finish(), so later torch draws are
+    unchanged as well. Falls back to torch.randint itself when the state layout is not the expected one or N >= 2^28 (from there on this
+    torch consumes two outputs per element).
+    device_rng=True draws on the GPU instead: no host work, different numbers."""
+
+    RING = 4
 
     def __init__(self, N, chunk, steps, device, device_rng=False):
+        device = torch.device(device)
         self.N, self.chunk, self.device, self.device_rng = N, chunk, device, device_rng
+        self.key = None
+        st = torch.get_rng_state()
+        if not _FAST_DRAWS or device_rng or device.type != "cuda" or not (0 < N < 2 ** 28) or st.numel() != _MT_BYTES or chunk <= 0:
+            return
+        w = st.view(torch.int64)
+        left, nxt = int(st.view(torch.int32)[_MT_LEFT]), int(w[_MT_NEXT])
+        if not (1 <= left <= _MT_WORDS + 1 and 0 <= nxt <= _MT_WORDS and (left == 1 or nxt + left - 1 == _MT_WORDS)):
+            return
+        self._st = st
+        self.key = w[_MT_STATE:_MT_STATE + _MT_WORDS].to(torch.int32).contiguous()      # the words are < 2^32: keep the low halves
+        self.left, self.next = C.c_int64(left), C.c_int64(nxt)
+        self.ring = [(torch.empty(chunk, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(self.RING)]
+        self.k = 0
 
-    def next(self):
+    def next_batch(self):
         if self.device_rng:
             return torch.randint(low=0, high=self.N, size=[self.chunk], device=self.device)
-        return torch.randint(low=0, high=self.N, size=[self.chunk]).to(self.device)
+        if self.key is None:
+            return torch.randint(low=0, high=self.N, size=[self.chunk]).to(self.device)
+        host, ev = self.ring[self.k % self.RING]
+        if self.k >= self.RING:
+            ev.synchronize()                             # the copy out of this buffer four steps ago
+        self.k += 1
+        L = _lib.lib()
+        _lib.check(L.c3dgs_mt19937_fill(self.key.data_ptr(), C.byref(self.left), C.byref(self.next), host.data_ptr(), self.chunk))
+        with torch.cuda.device(self.device):
+            raw = host.to(self.device, non_blocking=True)
+            ev.record()
+            out = torch.empty(self.chunk, dtype=torch.int64, device=self.device)
+            _lib.check(L.c3dgs_draws_to_indices(self.chunk, self.N, raw.data_ptr(), out.data_ptr(),
+                                                torch.cuda.current_stream(self.device).cuda_stream))
+        return out
+
+    def finish(self):
+        """Write the advanced generator state back to torch (call once, also on error paths)."""
+        if self.key is None:
+            return
+        w = self._st.view(torch.int64)
+        self._st.view(torch.int32)[_MT_LEFT] = self.left.value
+        w[_MT_NEXT] = self.next.value
+        w[_MT_STATE:_MT_STATE + _MT_WORDS] = self.key.to(torch.int64) & 0xffffffff
+        torch.set_rng_state(self._st)
+        self.key = None
 
 
 def _dist_info(group):
@@ -185,22 +237,26 @@ def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size:
     err_sums = []
     it = range(steps) if batches is None else range(len(batches))
     draws = None if batches is not None else _BatchDraws(N, vq_chunk, steps, dev, device_rng)
-    for s in it:
-        if batches is not None:
-            batch = batches[s].to(device=dev, dtype=torch.int64)
-        else:
-            batch = draws.next()
-            if world > 1:                                                           # every rank uses rank 0's draw
-                dist.broadcast(batch, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
-        B = int(batch.numel())
-        lo, hi = (rank * B) // world, ((rank + 1) * B) // world
-        with torch.no_grad():
-            _, S, dsum = vq_model.partial_sums(feats, imp, gather=batch[lo:hi].contiguous())
-            if world > 1:
-                dist.all_reduce(S, group=pg)
-                dist.all_reduce(dsum, group=pg)
-            vq_model.apply_sums(S, scale_normalize=scale_normalize)
-        err_sums.append((dsum, B))
+    try:
+        for s in it:
+            if batches is not None:
+                batch = batches[s].to(device=dev, dtype=torch.int64)
+            else:
+                batch = draws.next_batch()
+                if world > 1:                                                       # every rank uses rank 0's draw
+                    dist.broadcast(batch, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
+            B = int(batch.numel())
+            lo, hi = (rank * B) // world, ((rank + 1) * B) // world
+            with torch.no_grad():
+                _, S, dsum = vq_model.partial_sums(feats, imp, gather=batch[lo:hi].contiguous())
+                if world > 1:
+                    dist.all_reduce(S, group=pg)
+                    dist.all_reduce(dsum, group=pg)
+                vq_model.apply_sums(S, scale_normalize=scale_normalize)
+            err_sums.append((dsum, B))
+    finally:
+        if draws is not None:
+            draws.finish()
     gc.collect()
 
     start = time.time()

@@ -142,6 +142,16 @@ int c3dgs_vq_accumulate(int64_t B, int32_t K, int32_t D, const float* x, const f
 int c3dgs_vq_apply(int32_t K, int32_t D, const float* S, float* codebook, float* entry_importance,
                    float decay, float alpha, float eps, int32_t scale_normalize, void* stream);
 
+/* ---- batch draws of vq_features: `batch = torch.randint(low=0, high=N, size=[vq_chunk])` on the CPU generator
+ * (compression/vq.py:69) ----
+ * mt19937_fill (host only, no GPU): continues at::mt19937's stream by n tempered 32-bit outputs. state = the 624 key
+ * words, left / next = the generator's counters as torch.get_rng_state() serialises them (left == 1: block exhausted);
+ * all three are updated so the caller can write the advanced state back. `out` may be pinned host memory.
+ * draws_to_indices: out[i] = (int64) raw[i] % range on the device -- what torch's randint makes of each 32-bit output
+ * for range < 2^28 (ATen uniform_int_from_to; larger ranges consume 64 bits per element and are left to torch). */
+int c3dgs_mt19937_fill(uint32_t* state, int64_t* left, int64_t* next, uint32_t* out, int64_t n);
+int c3dgs_draws_to_indices(int64_t n, int64_t range, const uint32_t* raw, int64_t* out, void* stream);
+
 /* ---- L1 + SSIM loss (reference utils/loss_utils.py:17-63, used at finetune.py:48) ----
  * forward: sums[0..63] add up to sum |img - gt|, sums[64..127] to sum ssim_map (float64, device, zeroed by the callee;
  * 64 partial accumulators each so that the per-workgroup atomics do not serialise on one address); 11x11 Gaussian

@@ -103,7 +103,47 @@ def test_batch_draws_equal_reference_stream():
     ref = [torch.randint(low=0, high=1000, size=[37]) for _ in range(11)]
     torch.manual_seed(3)
     d = _BatchDraws(1000, 37, 11, "cpu")
-    assert all(torch.equal(a, d.next()) for a in ref)
+    assert all(torch.equal(a, d.next_batch()) for a in ref)
+
+
+@pytest.mark.parametrize("seed,N,sizes", [(3, 1000, [37, 1, 700, 623, 624, 625, 5000]), (0, 4_500_000, [2 ** 16, 3, 2 ** 12]),
+                                          (12345, 2 ** 28 - 1, [1000, 1249])])
+def test_mt19937_fill_continues_the_torch_cpu_generator(seed, N, sizes):
+    """csrc/draws.hip (host part): raw words % N == torch.randint's values, from any position inside a 624-word block,
+    and the written-back state makes torch continue exactly where it would have been."""
+    import ctypes as C
+    from c3dgs_amd import _lib, vq
+    L = _lib.lib()
+    torch.manual_seed(seed)
+    torch.rand(5)                                        # start somewhere inside a block
+    st0 = torch.get_rng_state()
+    ref = [torch.randint(low=0, high=N, size=[n]) for n in sizes]
+    after = torch.rand(7)
+    torch.set_rng_state(st0)
+    w = st0.clone().view(torch.int64)
+    key = w[vq._MT_STATE:vq._MT_STATE + 624].to(torch.int32).contiguous()
+    left, nxt = C.c_int64(int(w.view(torch.int32)[vq._MT_LEFT])), C.c_int64(int(w[vq._MT_NEXT]))
+    for n, r in zip(sizes, ref):
+        out = torch.empty(n, dtype=torch.int32)
+        _lib.check(L.c3dgs_mt19937_fill(key.data_ptr(), C.byref(left), C.byref(nxt), out.data_ptr(), n))
+        got = (out.to(torch.int64) & 0xffffffff) % N
+        assert torch.equal(got, r)
+    w.view(torch.int32)[vq._MT_LEFT] = left.value
+    w[vq._MT_NEXT] = nxt.value
+    w[vq._MT_STATE:vq._MT_STATE + 624] = key.to(torch.int64) & 0xffffffff
+    torch.set_rng_state(w.view(torch.uint8))
+    assert torch.equal(torch.rand(7), after)
+    # a freshly seeded generator (left == 1, nothing drawn yet)
+    torch.manual_seed(seed + 1)
+    w = torch.get_rng_state().view(torch.int64)
+    assert int(w.view(torch.int32)[vq._MT_LEFT]) == 1
+    key = w[vq._MT_STATE:vq._MT_STATE + 624].to(torch.int32).contiguous()
+    left, nxt = C.c_int64(1), C.c_int64(int(w[vq._MT_NEXT]))
+    out = torch.empty(10, dtype=torch.int32)
+    _lib.check(L.c3dgs_mt19937_fill(key.data_ptr(), C.byref(left), C.byref(nxt), out.data_ptr(), 10))
+    assert torch.equal((out.to(torch.int64) & 0xffffffff) % N, torch.randint(low=0, high=N, size=[10]))
+    bad = C.c_int64(700)
+    assert L.c3dgs_mt19937_fill(key.data_ptr(), C.byref(bad), C.byref(nxt), out.data_ptr(), 10) != 0
 
 
 def test_scratch_owner_dies_without_the_cycle_collector():

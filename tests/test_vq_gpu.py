@@ -116,3 +116,52 @@ def test_weighted_distance_full_size_properties(hip):
     assert (d[:4096, None] <= other * (1 + 1e-5) + 1e-7).all()
     d2, i2 = hip.weightedDistance(cb, cb)
     assert (d2 == 0).all() and (i2 == torch.arange(C, device="cuda")).all()
+
+
+def test_batch_draws_on_device_equal_the_cpu_generator_stream(hip):
+    """The Lloyd-step draws come from the library's MT19937 continuation + `% N` on the GPU (csrc/draws.hip): same numbers
+    as `torch.randint(0, N, [chunk])` on the CPU default generator (reference vq.py:69), more steps than the pinned ring
+    holds, and the torch generator ends where the reference's loop would leave it."""
+    from c3dgs_amd.vq import _BatchDraws
+    N, chunk, steps = 4_500_123, 70_001, 11
+    torch.manual_seed(21)
+    torch.rand(3)
+    ref = [torch.randint(low=0, high=N, size=[chunk]) for _ in range(steps)]
+    after = torch.rand(4)
+    torch.manual_seed(21)
+    torch.rand(3)
+    d = _BatchDraws(N, chunk, steps, torch.device("cuda", 0))
+    assert d.key is not None                             # the fast path is the one under test
+    got = [d.next_batch() for _ in range(steps)]
+    d.finish()
+    for a, b in zip(ref, got):
+        assert b.dtype == torch.int64 and torch.equal(a, b.cpu())
+    assert torch.equal(torch.rand(4), after)
+
+
+def test_vq_features_default_draws_equal_explicit_batches(hip):
+    """vq_features with the library's MT19937 continuation == vq_features calling torch.randint per step, as the reference
+    does (up to the order of the float atomics in the centroid sums)."""
+    from c3dgs_amd import vq as vqm
+    g = torch.Generator().manual_seed(1)
+    N, D, K, steps, chunk = 20_000, 6, 64, 9, 2 ** 11
+    f = (torch.randn(N, D, generator=g) * 0.1).float().cuda()
+    f[:, [0, 3, 5]] = f[:, [0, 3, 5]].abs() + 0.2
+    imp = torch.rand(N, generator=g).pow(4).float().cuda()
+    init = torch.rand(K, D, generator=g)
+    torch.manual_seed(77)
+    vqm._FAST_DRAWS = False
+    try:
+        cb_a, idx_a = hip.vq_features(f, imp, K, chunk, steps, init_rand=init, silent=True, scale_normalize=True)
+    finally:
+        vqm._FAST_DRAWS = True
+    end_a = torch.rand(3)
+    torch.manual_seed(77)
+    cb_b, idx_b = hip.vq_features(f, imp, K, chunk, steps, init_rand=init, silent=True, scale_normalize=True)
+    assert torch.equal(torch.rand(3), end_a)             # the torch generator is left in the same state
+    assert torch.allclose(cb_a, cb_b, rtol=1e-4, atol=1e-6)
+    assert (idx_a == idx_b).float().mean() >= 0.999
+    # and a different seed really gives different draws (the comparison above is not vacuous)
+    torch.manual_seed(78)
+    cb_c, _ = hip.vq_features(f, imp, K, chunk, steps, init_rand=init, silent=True, scale_normalize=True)
+    assert not torch.allclose(cb_a, cb_c, rtol=1e-4, atol=1e-6)
