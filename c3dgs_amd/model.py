@@ -660,20 +660,42 @@ class GaussianModel:
         else:
             colors_precomp = override_color
         visible = rasterizer.markVisible(means3D, extrinsic_vector=settings.extrinsic_vector)
-        pick = lambda t: None if t is None else t[visible]
+        # `t[visible]` of the reference (gaussian_model.py:851-862) for every input, from ONE nonzero: a boolean-mask index
+        # runs nonzero (with its host sync) per tensor, and its backward is a sort-based index_put(accumulate) -- 2 ms
+        # per tensor for 6M rows -- although the rows are unique.
+        rows = visible.nonzero(as_tuple=False).squeeze(1)
+        pick = lambda t: None if t is None else (_MaskGather.apply(t, rows) if t.requires_grad else t.index_select(0, rows))  # noqa: E731
         if indexed:
-            image, radii = rasterizer(means3D=means3D[visible], means2D=screenspace_points[visible], shs=shs,
-                                      sh_indices=self._feature_indices[visible], g_indices=self._gaussian_indices[visible],
-                                      colors_precomp=None, opacities=opacity[visible], scales=scales,
-                                      scale_factors=scale_factors[visible], rotations=rotations,
+            image, radii = rasterizer(means3D=pick(means3D), means2D=pick(screenspace_points), shs=shs,
+                                      sh_indices=pick(self._feature_indices), g_indices=pick(self._gaussian_indices),
+                                      colors_precomp=None, opacities=pick(opacity), scales=scales,
+                                      scale_factors=pick(scale_factors), rotations=rotations,
                                       cov3D_precomp=pick(cov3D_precomp), extrinsic_vector=settings.extrinsic_vector)
         else:
-            image, radii = rasterizer(means3D=means3D[visible], means2D=screenspace_points[visible], shs=pick(shs),
-                                      colors_precomp=pick(colors_precomp), opacities=opacity[visible], scales=pick(scales),
+            image, radii = rasterizer(means3D=pick(means3D), means2D=pick(screenspace_points), shs=pick(shs),
+                                      colors_precomp=pick(colors_precomp), opacities=pick(opacity), scales=pick(scales),
                                       rotations=pick(rotations), cov3D_precomp=pick(cov3D_precomp),
                                       extrinsic_vector=settings.extrinsic_vector)
         return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
                 "visible": visible}
+
+
+class _MaskGather(torch.autograd.Function):
+    """t[mask] with the row numbers of the mask given: forward index_select, backward a plain scatter into zeros (the rows
+    are unique, nothing accumulates)."""
+
+    @staticmethod
+    def forward(ctx, t, rows):
+        ctx.save_for_backward(rows)
+        ctx.n = t.shape[0]
+        return t.index_select(0, rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        (rows,) = ctx.saved_tensors
+        out = g.new_zeros((ctx.n,) + tuple(g.shape[1:]))
+        out.index_copy_(0, rows, g.contiguous())
+        return out, None
 
 
 def _covariance(scaling, scaling_modifier, rotation, strip_sym=True):
@@ -684,7 +706,10 @@ def _covariance(scaling, scaling_modifier, rotation, strip_sym=True):
                      2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
                      2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
     L = R * (scaling_modifier * scaling)[:, None, :]
-    cov = L @ L.transpose(1, 2)
-    if not strip_sym:
-        return cov
-    return torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], dim=1)
+    # L @ L^T written out: a batched 3x3 GEMM of millions of matrices runs at a few GB/s in the BLAS library (52 ms for 6M)
+    r0, r1, r2 = L[:, 0], L[:, 1], L[:, 2]
+    sym = torch.stack([(r0 * r0).sum(1), (r0 * r1).sum(1), (r0 * r2).sum(1), (r1 * r1).sum(1), (r1 * r2).sum(1),
+                       (r2 * r2).sum(1)], dim=1)
+    if strip_sym:
+        return sym
+    return sym[:, [0, 1, 2, 1, 3, 4, 2, 4, 5]].reshape(-1, 3, 3)

@@ -166,3 +166,32 @@ def test_scratch_owner_dies_without_the_cycle_collector():
         assert wt() is None
     finally:
         gc.enable()
+
+
+def test_covariance_written_out_equals_matmul_form_and_mask_gather_equals_boolean_index():
+    """model._covariance replaces the reference's batched `L @ L.transpose(1, 2)` (gaussian_model.py:55-64) by the six
+    written-out products; model._MaskGather replaces `t[mask]` (gaussian_model.py:851-862) -- same values, same gradients."""
+    from c3dgs_amd import model
+    g = torch.Generator().manual_seed(4)
+    s = torch.rand(500, 3, generator=g) + 0.1
+    q = torch.randn(500, 4, generator=g)
+    r = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+                     1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+                     1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+    L = R * (1.3 * s)[:, None, :]
+    full = L @ L.transpose(1, 2)
+    assert torch.allclose(model._covariance(s, 1.3, q, strip_sym=False), full, rtol=1e-5, atol=1e-6)
+    sym = model._covariance(s, 1.3, q)
+    assert torch.allclose(sym, torch.stack([full[:, 0, 0], full[:, 0, 1], full[:, 0, 2], full[:, 1, 1], full[:, 1, 2],
+                                            full[:, 2, 2]], 1), rtol=1e-5, atol=1e-6)
+    t1 = torch.randn(500, 4, 3, generator=g, requires_grad=True)
+    t2 = t1.detach().clone().requires_grad_(True)
+    mask = torch.rand(500, generator=g) < 0.4
+    a = model._MaskGather.apply(t1, mask.nonzero().squeeze(1))
+    b = t2[mask]
+    assert torch.equal(a, b)
+    wgt = torch.randn(a.shape, generator=g)
+    (a * wgt).sum().backward(); (b * wgt).sum().backward()
+    assert torch.equal(t1.grad, t2.grad)
