@@ -224,7 +224,10 @@ def main():
 
     # ---- the same step with the fused L1+SSIM loss producing dL/dimage (QAT inner loop of finetune.py:40-49 without the
     # optimizer / FakeQuantize glue): extra, not the headline
+    # (single-GPU extras: with N replicas they would only repeat the headline's weak scaling, behind more barriers)
     try:
+        if world > 1:
+            raise _SkipExtra()
         from c3dgs_amd import loss as lossm
         gt = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
 
@@ -245,6 +248,8 @@ def main():
             qat_step()
         torch.cuda.synchronize()
         out["qat_loop"] = {"metric": "views/s render + fused L1+SSIM loss + backward", "value": world * args.steps / (time.perf_counter() - tq)}
+    except _SkipExtra:
+        pass
     except Exception as e:
         out["qat_loop"] = {"error": repr(e)}
 
@@ -252,7 +257,11 @@ def main():
     # [visible] gathers) + raster + fused loss + backward -- through c3dgs_amd.model.GaussianModel.render (fused glue),
     # next to the reference's composition of the same glue from torch ops / torch.ao modules around the same rasterizer
     try:
+        if world > 1:
+            raise _SkipExtra()
         out["qat_model"] = bench_qat_model(c3dgs_amd, _lib, dev, ix_cpu, intr, evd, W, H, args.steps, barrier, world)
+    except _SkipExtra:
+        pass
     except Exception as e:
         out["qat_model"] = {"error": repr(e)}
 
@@ -274,6 +283,10 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+class _SkipExtra(Exception):
+    pass
 
 
 def bench_qat_model(c3dgs_amd, _lib, dev, ix_cpu, intr, evd, W, H, steps, barrier, world):
