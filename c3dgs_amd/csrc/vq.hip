@@ -268,34 +268,40 @@ wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
     }
 }
 
-// exact re-scan of the flagged points: one wave per flagged point, 64 lanes split the codewords, k-ordered FMA
-// chain per codeword, then a wave argmin that prefers the lower index on ties (== the sequential strict '<').
+// exact re-scan of the flagged points. A workgroup owns 64 consecutive points; for every flagged one its 256 threads
+// split the codewords (thread t takes t, t+256, ...: k-ordered FMA chain per codeword, strict '<' per thread keeps its
+// lowest index), then a wave + LDS argmin that prefers the lower index on ties (== the sequential strict '<').
+// (One wave per flagged point took 60-140 us per Lloyd step for ~1 % flagged points; the flagged points are few but each
+// costs a full codebook pass, so the latency of one pass is what the launch lasts.)
 template <int K>
 __global__ void __launch_bounds__(256)
 wd_fixup_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather,
                 const float* __restrict__ codebook, float* __restrict__ out_dist, int64_t* __restrict__ out_idx)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave_id = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int64_t n0 = wave_id * 64;
+    __shared__ float s_best[4];
+    __shared__ int s_besti[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
     if (n0 >= N) return;
     const int64_t n = n0 + lane;
-    const bool flagged = n < N && out_idx[n] < 0;
-    unsigned long long m = __ballot(flagged);
+    unsigned long long m = __ballot(n < N && out_idx[n] < 0);      // every wave computes the same mask
     while (m) {
         const int l = __builtin_ctzll(m);
         m &= m - 1;
         const int64_t np = n0 + l;
         const int64_t row = gather ? gather[np] : np;
         const float* x = coefs + row * K;
+        float xr[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) xr[k] = x[k];
         float best = FLT_MAX;
         int besti = 0x7fffffff;
-        for (int c = lane; c < C; c += 64) {
+        for (int c = tid; c < C; c += 256) {
             const float* cb = codebook + (size_t)c * K;
             float r = 0.f;
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const float d = x[k] - cb[k];
+                const float d = xr[k] - cb[k];
                 r = fmaf(d, d, r);
             }
             if (r < best) { best = r; besti = c; }
@@ -306,7 +312,16 @@ wd_fixup_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t
             const int oi = __shfl_xor(besti, o);
             if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
         }
-        if (lane == 0) { out_dist[np] = best; out_idx[np] = (int64_t)(besti == 0x7fffffff ? 0 : besti); }
+        __syncthreads();                                             // previous round's s_best has been read
+        if (lane == 0) { s_best[wave] = best; s_besti[wave] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 1; w < 4; w++)
+                if (s_best[w] < best || (s_best[w] == best && s_besti[w] < besti)) { best = s_best[w]; besti = s_besti[w]; }
+            out_dist[np] = best;
+            out_idx[np] = (int64_t)(besti == 0x7fffffff ? 0 : besti);
+        }
     }
 }
 
@@ -319,7 +334,7 @@ int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const 
     const bool al16 = (((uintptr_t)coefs | (uintptr_t)codebook) & 15) == 0;
     const bool al8 = (((uintptr_t)coefs | (uintptr_t)codebook) & 7) == 0;
     static const bool force_exact = getenv("C3DGS_VQ_EXACT_VALU") != nullptr;   // A/B switch for tests and profiling
-    const unsigned g1 = (unsigned)((N + 4 * MF_PTS - 1) / (4 * MF_PTS)), g2 = (unsigned)((N + 255) / 256);
+    const unsigned g1 = (unsigned)((N + 4 * MF_PTS - 1) / (4 * MF_PTS)), g2 = (unsigned)((N + 63) / 64);
     if (K == 48 && al16 && C >= 32 && !force_exact) {
         wd_mfma_kernel<48><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
         wd_fixup_kernel<48><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
