@@ -253,6 +253,18 @@ def main():
     except Exception as e:
         out["qat_loop"] = {"error": repr(e)}
 
+    # ---- the headline step again with the index layout compression/vq.py produces (join_features, vq.py:90-103): most
+    # Gaussians point into the 4096-row VQ codebook, the kept ones own one row each, in Gaussian order. synth-v1's indices
+    # (the headline) are uniformly random over the whole codebook -- the worst case for the codebook gathers.
+    try:
+        if world > 1:
+            raise _SkipExtra()
+        out["postvq_index_layout"] = bench_postvq_layout(step, t, P, args.steps, dev, _lib)
+    except _SkipExtra:
+        pass
+    except Exception as e:
+        out["postvq_index_layout"] = {"error": repr(e)}
+
     # ---- the whole QAT view from the RAW parameters -- getters (activations + FakeQuantize observers +
     # [visible] gathers) + raster + fused loss + backward -- through c3dgs_amd.model.GaussianModel.render (fused glue),
     # next to the reference's composition of the same glue from torch ops / torch.ao modules around the same rasterizer
@@ -283,6 +295,42 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_postvq_layout(step, t, P, steps, dev, _lib):
+    """Same scene, same codebook sizes; only sh_indices / g_indices change (and so which rows the kernels gather)."""
+    g = torch.Generator().manual_seed(17)
+
+    def layout(n_rows, n_vq=4096):
+        kept = max(min(n_rows - n_vq, P), 0)                      # rows past the VQ codebook: one per kept Gaussian
+        idx = torch.randint(0, min(n_vq, n_rows), (P,), generator=g, dtype=torch.int64)
+        if kept:
+            who = torch.randperm(P, generator=g)[:kept].sort().values
+            idx[who] = n_vq + torch.arange(kept, dtype=torch.int64)
+        return idx.to(dev)
+
+    saved = t["sh_indices"], t["g_indices"]
+    try:
+        t["sh_indices"], t["g_indices"] = layout(t["shs"].shape[0]), layout(t["scales"].shape[0])
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        _lib.profile_enable(True)
+        _lib.profile_read()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        st = _lib.profile_read()
+        _lib.profile_enable(False)
+    finally:
+        t["sh_indices"], t["g_indices"] = saved
+    return {"metric": "views/s fwd+bwd, indices as join_features lays them out", "value": steps / el, "ms_per_step": 1e3 * el / steps,
+            "stages_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(st.items(), key=lambda kv: -kv[1][0])[:6]}}
 
 
 class _SkipExtra(Exception):
