@@ -153,11 +153,13 @@ def main():
     # average over these same K launches)
     _lib.profile_enable(True, only=dom)
     _lib.profile_read()
+    n_alloc = torch.cuda.memory_stats(dev)["num_device_alloc"]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    n_alloc = torch.cuda.memory_stats(dev)["num_device_alloc"] - n_alloc
     dom_live = _lib.profile_read()
     _lib.profile_enable(False)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -217,6 +219,7 @@ def main():
         "stages_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])},
         # informational: kernels of one step (untimed profiling pass) vs the timed step. A ratio far above 1 means the
         # GPU sat idle waiting for the host during the timed region (seen once on a heavily loaded box: profiles/README.md)
+        "device_allocs_in_timed_region": n_alloc,     # hipMalloc calls of the caching allocator (expected: 0)
         "step_over_kernel_time": (1e3 * elapsed / args.steps) / max(sum(v for k, v in stage_ms.items() if k in raster_names), 1e-9),
         "view_alg_bytes": view_bytes,
         "view_hbm_frac": view_bytes * (args.steps / elapsed) / 1e9 / HBM_PEAK_GBS,
@@ -312,14 +315,23 @@ def bench_postvq_layout(step, t, P, steps, dev, _lib):
     saved = t["sh_indices"], t["g_indices"]
     try:
         t["sh_indices"], t["g_indices"] = layout(t["shs"].shape[0]), layout(t["scales"].shape[0])
-        for _ in range(4):
+        prev = None
+        for k in range(40):                                        # until the step time has settled (as for the headline)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
             step()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            cur = time.perf_counter() - tp
+            if k >= 5 and prev is not None and abs(cur - prev) <= 0.05 * min(cur, prev):
+                break
+            prev = cur
+        n_alloc = torch.cuda.memory_stats(dev)["num_device_alloc"]
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        n_alloc = torch.cuda.memory_stats(dev)["num_device_alloc"] - n_alloc
         _lib.profile_enable(True)
         _lib.profile_read()
         for _ in range(5):
@@ -330,6 +342,7 @@ def bench_postvq_layout(step, t, P, steps, dev, _lib):
     finally:
         t["sh_indices"], t["g_indices"] = saved
     return {"metric": "views/s fwd+bwd, indices as join_features lays them out", "value": steps / el, "ms_per_step": 1e3 * el / steps,
+            "device_allocs_in_timed_loop": n_alloc,
             "stages_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(st.items(), key=lambda kv: -kv[1][0])[:6]}}
 
 

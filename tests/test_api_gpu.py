@@ -142,3 +142,41 @@ def test_steady_state_makes_no_device_allocations(hip):
         assert torch.cuda.memory_reserved() == r0
     finally:
         gc.enable()
+
+
+def test_module_path_makes_no_device_allocations_in_steady_state(hip):
+    """The autograd module path bench.py drives (markVisible + GaussianRasterizerIndexed + backward): nothing a step
+    allocates may survive it through a reference cycle."""
+    import gc
+    sc = synth.scene(20000, 640, 360, 400.0, seed=3, scale_median=0.02)
+    ix = {k: v.cuda() for k, v in synth.index_scene(sc, shs_extra=64, gs_extra=64).items()}
+    intr, ev = synth.camera(640, 360, 400.0)
+    rast = hip.GaussianRasterizerIndexed(_settings(hip, intr, ev), optimize_camera=True)
+    leaves = {k: ix[k].clone().requires_grad_() for k in ("means3D", "opacities", "shs", "scales", "scale_factors", "rotations")}
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    evd = ev.cuda().requires_grad_()
+    dL = synth.grad_image(640, 360).cuda()
+
+    def step():
+        for v in leaves.values():
+            v.grad = None
+        means2D.grad = None
+        evd.grad = None
+        rast.markVisible(leaves["means3D"], extrinsic_vector=evd)
+        color, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                            sh_indices=ix["sh_indices"], g_indices=ix["g_indices"], shs=leaves["shs"], scales=leaves["scales"],
+                            scale_factors=leaves["scale_factors"], rotations=leaves["rotations"], extrinsic_vector=evd)
+        torch.autograd.backward(color, dL)
+
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(5):
+            step()
+        n0, r0 = torch.cuda.memory_stats()["num_device_alloc"], torch.cuda.memory_reserved()
+        for _ in range(12):
+            step()
+        assert torch.cuda.memory_stats()["num_device_alloc"] == n0
+        assert torch.cuda.memory_reserved() == r0
+    finally:
+        gc.enable()
