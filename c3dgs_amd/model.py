@@ -6,7 +6,7 @@ Mirrors, for the render path only, scene/gaussian_model.py:
     get_scaling ... get_opacity                   :213-267
     GaussianModel.render                          :766-886
     FakeQuantizationHalf                          :1405-1414
-Densification, optimizer plumbing, ply / npz IO of the reference class are outside the hot path and not mirrored.
+Densification and ply IO of the reference class are outside the hot path and not mirrored.
 
 The reference evaluates every getter with torch ops and seven torch.ao FakeQuantize modules: about a hundred small
 launches and twenty host syncs per view (aminmax + float(scale) / int(zero_point) per module, one nonzero per
@@ -335,6 +335,9 @@ class GaussianModel:
                 self._modules_qa[k].disable_observer()
             self.xyz_qa = lambda x: x
         self._count_host = None
+        self.spatial_lr_scale = 0.0                             # set by the scene loader in the reference (gaussian_model.py:286)
+        self.optimizer = None
+        self.xyz_scheduler_args = None
         # activations, gaussian_model.py:54-77
         if use_factor_scaling:
             self.scaling_activation = lambda x: torch.nn.functional.normalize(torch.nn.functional.relu(x))
@@ -580,6 +583,38 @@ class GaussianModel:
         self.active_sh_degree = self.max_sh_degree
         return self
 
+    # ---- optimizer plumbing of the fine-tuning loop (gaussian_model.py:292-322)
+    def training_setup(self, training_args):
+        """Same parameter groups, names and learning rates as the reference; the optimizer is the fused Adam
+        (c3dgs_amd.optim.Adam, one launch for all groups) instead of torch.optim.Adam(l, lr=0.0, eps=1e-15)."""
+        from . import optim
+        self.percent_dense = training_args.percent_dense
+        n = self._xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=self.device)
+        self.denom = torch.zeros((n, 1), device=self.device)
+        groups = [
+            {"params": [self._xyz], "lr": training_args.position_lr_init * self.spatial_lr_scale, "name": "xyz"},
+            {"params": [self._features_dc], "lr": training_args.feature_lr, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": training_args.feature_lr / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": training_args.opacity_lr, "name": "opacity"},
+            {"params": [self._scaling], "lr": training_args.scaling_lr, "name": "scaling"},
+            {"params": [self._rotation], "lr": training_args.rotation_lr, "name": "rotation"},
+        ]
+        if self._scaling_factor is not None:
+            groups.append({"params": [self._scaling_factor], "lr": training_args.scaling_lr, "name": "scaling_factor"})
+        self.optimizer = optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.xyz_scheduler_args = get_expon_lr_func(
+            lr_init=training_args.position_lr_init * self.spatial_lr_scale,
+            lr_final=training_args.position_lr_final * self.spatial_lr_scale,
+            lr_delay_mult=training_args.position_lr_delay_mult, max_steps=training_args.position_lr_max_steps)
+
+    def update_learning_rate(self, iteration):
+        for param_group in self.optimizer.param_groups:
+            if param_group["name"] == "xyz":
+                lr = self.xyz_scheduler_args(iteration)
+                param_group["lr"] = lr
+                return lr
+
     # ---- render (gaussian_model.py:766-886)
     def render(self, viewpoint_camera, pipe, bg_color, scaling_modifier=1.0, override_color=None, clamp_color=True,
                cov3d=None):
@@ -696,6 +731,22 @@ class _MaskGather(torch.autograd.Function):
         out = g.new_zeros((ctx.n,) + tuple(g.shape[1:]))
         out.index_copy_(0, rows, g.contiguous())
         return out, None
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """utils/general_utils.py:32-65: log-linear interpolation from lr_init (step 0) to lr_final (step max_steps), optionally
+    eased in over lr_delay_steps; 0 for negative steps or when both rates are 0."""
+    import math
+
+    def rate(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        delay = 1.0
+        if lr_delay_steps > 0:
+            delay = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+        t = min(max(step / max_steps, 0.0), 1.0)
+        return delay * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+    return rate
 
 
 def _covariance(scaling, scaling_modifier, rotation, strip_sym=True):

@@ -195,3 +195,23 @@ def test_covariance_written_out_equals_matmul_form_and_mask_gather_equals_boolea
     wgt = torch.randn(a.shape, generator=g)
     (a * wgt).sum().backward(); (b * wgt).sum().backward()
     assert torch.equal(t1.grad, t2.grad)
+
+
+def test_pipeline_parameter_defaults_and_lr_schedule():
+    """arguments/__init__.py:85-136 defaults; utils/general_utils.py:32-65 schedule (values computed from the formula)."""
+    import math
+    from c3dgs_amd import model, pipeline
+    o, c = pipeline.OptimizationParams(), pipeline.CompressionParams(finetune_iterations=7)
+    assert (o.position_lr_init, o.position_lr_final, o.position_lr_max_steps, o.feature_lr, o.lambda_dssim) == \
+        (0.00016, 0.0000016, 30_000, 0.0025, 0.2)
+    assert (c.color_codebook_size, c.gaussian_batch_size, c.gaussian_cluster_iterations, c.finetune_iterations) == \
+        (4096, 2 ** 20, 800, 7)
+    with pytest.raises(TypeError):
+        pipeline.CompressionParams(no_such_parameter=1)
+    f = model.get_expon_lr_func(1.6e-4, 1.6e-6, lr_delay_mult=0.01, max_steps=30_000)
+    assert f(0) == pytest.approx(1.6e-4) and f(30_000) == pytest.approx(1.6e-6) and f(10 ** 6) == pytest.approx(1.6e-6)
+    assert f(15_000) == pytest.approx(math.sqrt(1.6e-4 * 1.6e-6)) and f(-1) == 0.0
+    assert model.get_expon_lr_func(0.0, 0.0)(5) == 0.0
+    g = model.get_expon_lr_func(1e-2, 1e-4, lr_delay_steps=100, lr_delay_mult=0.1, max_steps=1000)
+    assert g(0) == pytest.approx(1e-2 * 0.1)
+    assert g(50) == pytest.approx((0.1 + 0.9 * math.sin(0.25 * math.pi)) * math.exp(math.log(1e-2) * 0.95 + math.log(1e-4) * 0.05))

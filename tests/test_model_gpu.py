@@ -375,3 +375,98 @@ def test_training_iteration_makes_no_device_allocations_in_steady_state():
         assert torch.cuda.memory_reserved() == r0
     finally:
         gc.enable()
+
+
+def test_finetune_loop_follows_the_reference_schedule(tmp_path):
+    """c3dgs_amd.pipeline.finetune (finetune.py:10-66): cameras popped with Python's `random` like the reference, the xyz
+    learning rate follows the schedule, no optimizer step after the last iteration, and the loss goes down."""
+    import random
+    from c3dgs_amd import pipeline
+    from c3dgs_amd.model import PipelineParams
+    W, H = 320, 200
+    raw = _raw(9, P=6000, W=W, H=H)
+    target = _model(raw)
+    cams = []
+    for k in range(3):
+        intr, ev = synth.camera(W, H, 300.0, extrinsic_vector=(0.0, 0.02 * k, 0.0, 1.0, 0.01 * k, 0.0, 0.0))
+        cam = _Cam(intr, ev)
+        with torch.no_grad():
+            cam.original_image = target.render(cam, PipelineParams(), torch.zeros(3, device=DEV))["render"].clone()
+        cams.append(cam)
+    noisy = dict(raw)
+    g = torch.Generator().manual_seed(2)
+    noisy["features_dc"] = raw["features_dc"] + 0.3 * torch.randn(raw["features_dc"].shape, generator=g)
+    m = _model(noisy)
+    m.spatial_lr_scale = 2.0
+
+    class Scene:
+        loaded_iter = 5
+        gaussians = m
+
+        def getTrainCameras(self):
+            return cams
+
+    seen, logged = [], []
+    orig_render = m.render
+
+    def spy(cam, *a, **k):
+        seen.append(cams.index(cam))
+        return orig_render(cam, *a, **k)
+
+    m.render = spy
+    opt, comp = pipeline.OptimizationParams(position_lr_max_steps=100), pipeline.CompressionParams(finetune_iterations=20)
+    random.seed(4)
+    ema = pipeline.finetune(Scene(), pipeline._Dataset(), opt, comp, PipelineParams(), log=lambda it, v: logged.append((it, v)))
+    # the reference's camera order for this seed
+    random.seed(4)
+    want, stack = [], []
+    for _ in range(20):
+        if not stack:
+            stack = list(range(3))
+        want.append(stack.pop(random.randint(0, len(stack) - 1)))
+    assert seen == want
+    assert [it for it, _ in logged] == [10, 20, 25] and logged[-1][1] == ema and logged[-1][1] < logged[0][1]
+    lr = [gq["lr"] for gq in m.optimizer.param_groups if gq["name"] == "xyz"][0]
+    assert lr == pytest.approx(m.xyz_scheduler_args(25)) and lr == pytest.approx(2.0 * 1.6e-4 * (0.01 ** 0.25), rel=1e-6)
+    assert [gq["name"] for gq in m.optimizer.param_groups] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "scaling_factor"]
+    # 19 optimizer steps for 20 iterations, and the last iteration's gradients are still there
+    assert all(int(st["step"]) == 19 for st in m.optimizer.state.values())
+    assert m._features_dc.grad is not None
+
+
+def test_run_vq_composes_the_compression_run(tmp_path):
+    """c3dgs_amd.pipeline.run_vq (compress.py:202-290) on a small dense scene: sensitivity -> prune + VQ -> fine-tune ->
+    npz; the file loads back into a model that renders close to the uncompressed one."""
+    import os
+    from c3dgs_amd import pipeline
+    from c3dgs_amd.model import GaussianModel, PipelineParams
+    W, H, P = 320, 200, 6000
+    sc = synth.scene(P, W, H, 300.0, seed=21, sh_degree=3, scale_median=0.03)
+    op = sc["opacities"].clamp(1e-6, 1 - 1e-6)
+    norm = sc["scales"].norm(dim=1, keepdim=True)
+    g = GaussianModel(3, quantization=True, device=DEV)
+    g.set_tensors(xyz=sc["means3D"], features_dc=sc["shs"][:, :1], features_rest=sc["shs"][:, 1:], scaling=sc["scales"] / norm,
+                  rotation=sc["rotations"], opacity=torch.log(op / (1 - op)), scaling_factor=torch.log(norm))
+    g.spatial_lr_scale = 1.0
+    pipe, bg = PipelineParams(), torch.zeros(3, device=DEV)
+    cams = []
+    for k in range(3):
+        intr, ev = synth.camera(W, H, 300.0, extrinsic_vector=(0.0, 0.03 * (k - 1), 0.0, 1.0, 0.0, 0.0, 0.0))
+        cam = _Cam(intr, ev)
+        with torch.no_grad():
+            cam.original_image = g.render(cam, pipe, bg)["render"].clone()
+        cams.append(cam)
+    comp = pipeline.CompressionParams(finetune_iterations=6, color_cluster_iterations=8, gaussian_cluster_iterations=8,
+                                      color_codebook_size=64, gaussian_codebook_size=64, color_batch_size=2 ** 11,
+                                      gaussian_batch_size=2 ** 11, output_vq=str(tmp_path / "vq"))
+    timings, path = pipeline.run_vq(g, cams, pipeline.OptimizationParams(), pipe, comp)
+    assert set(timings) == {"sensitivity_calculation", "clustering", "finetune", "encode", "total"}
+    assert os.path.isfile(path) and path.endswith("point_cloud/iteration_6/point_cloud.npz")
+    assert os.path.isfile(os.path.join(comp.output_vq, "times.json")) and os.path.isfile(os.path.join(comp.output_vq, "cfg_args_comp"))
+    assert g.is_color_indexed and g.is_gaussian_indexed and g._xyz.shape[0] <= P
+    back = GaussianModel(3, quantization=True, device=DEV).load_npz(path)
+    with torch.no_grad():
+        a = back.render(cams[1], pipe, bg)["render"]
+    mse = float(((a - cams[1].original_image) ** 2).mean())
+    assert -10 * np.log10(mse) > 25.0, mse
+    assert os.path.getsize(path) < P * 59 * 4 / 8          # well under an eighth of the fp32 payload
