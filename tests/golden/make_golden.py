@@ -13,6 +13,7 @@ What it pins; the fixtures hold data only (inputs + exp
   morton.npz     mortonEncode/splitBy3 (scene/gaussian_model.py:1417-1432) on _sort_morton's quantisation (:999-1003)
   splats.npz     utils/splats.py: extract_rot_scale(to_full_cov(cov6)) and build_covariance of its result (pure torch,
                  importable): the eigendecomposition step of compress_covariance (compression/vq.py:186)
+  lr.npz         utils/general_utils.py:get_expon_lr_func (the xyz learning-rate schedule of finetune.py's loop)
   camgrad.npz    the closed-form grad_params block of _RasterizeGaussiansIndexedCamera.backward
                  (diff_gaussian_rasterization_no_camera/__init__.py:674-844), executed on CPU tensors
 """
@@ -203,7 +204,23 @@ def gen_loss():
     print("loss.npz")
 
 
+def gen_lr():
+    """utils/general_utils.py:get_expon_lr_func, the xyz learning-rate schedule of the fine-tuning loop (pure numpy)."""
+    sys.path.insert(0, REF)
+    from utils.general_utils import get_expon_lr_func
+    params = np.array([[1.6e-4, 1.6e-6, 0, 0.01, 30000], [3.2e-4, 3.2e-6, 0, 0.01, 100], [1e-2, 1e-4, 100, 0.1, 1000],
+                       [0.0, 0.0, 0, 1.0, 1000]], dtype=np.float64)       # lr_init, lr_final, delay_steps, delay_mult, max_steps
+    steps = np.array([-1, 0, 1, 10, 25, 50, 100, 999, 1000, 5000, 30000, 10 ** 6], dtype=np.int64)
+    values = np.array([[float(get_expon_lr_func(a, b, lr_delay_steps=int(d), lr_delay_mult=m, max_steps=int(n))(int(st)))
+                        for st in steps] for a, b, d, m, n in params])
+    np.savez_compressed(os.path.join(OUT, "lr.npz"), params=params, steps=steps, values=values)
+    print("lr.npz")
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["lr"]:
+        gen_lr()
+        sys.exit(0)
     vq = shim_and_import_vq()
     gen_vq(vq, "vq_color.npz", N=3000, D=12, K=64, steps=12, chunk=1024, scale_normalize=False, seed=0)
     gen_vq(vq, "vq_cov.npz", N=2500, D=6, K=32, steps=10, chunk=512, scale_normalize=True, seed=1)
@@ -213,3 +230,4 @@ if __name__ == "__main__":
     gen_loss()
     gen_morton()
     gen_splats()
+    gen_lr()

@@ -65,3 +65,13 @@ def test_morton_codes_vs_reference(orc):
     np.testing.assert_array_equal(codes, d["codes"])
     perm = orc.morton_order(d["xyz"])
     assert np.all(np.diff(codes[perm]) >= 0) and sorted(perm.tolist()) == list(range(len(codes)))
+
+
+def test_lr_schedule_matches_reference_golden():
+    """c3dgs_amd.model.get_expon_lr_func vs utils/general_utils.py:get_expon_lr_func executed by make_golden.py."""
+    from c3dgs_amd import model
+    z = _load("lr.npz")
+    for (a, b, d, m, n), want in zip(z["params"], z["values"]):
+        f = model.get_expon_lr_func(float(a), float(b), lr_delay_steps=int(d), lr_delay_mult=float(m), max_steps=int(n))
+        got = np.array([f(int(st)) for st in z["steps"]])
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
