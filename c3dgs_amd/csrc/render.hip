@@ -438,7 +438,6 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)row.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)row.w) };
             float v[64];
             v[63] = 0.f;                                         // pad: 7 x 9 = 63 values
-            int jv = -1;                                         // lane g remembers the batch entry of group slot g
 #pragma unroll
             for (int g = 0; g < GROUP_G; g++) {
                 const int j = (int)((rw[g >> 1] >> ((g & 1) * 16)) & 0xffffu);
@@ -471,13 +470,13 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                 v[g * NPART + 6] = wx * dx;
                 v[g * NPART + 7] = wx * dy;
                 v[g * NPART + 8] = wy * dy;
-                if (lane == g) jv = j < BATCH ? j : -1;
             }
             const float total = transpose_reduce_64(v, lane);
-            const int myj = __shfl(jv, my_g);                    // batch entry of the slot this lane's value belongs to
+            // batch entry of the group slot this lane's reduced value belongs to (slot 7 of a row is padding: my_idx 63)
+            const int myj = (int)s_list[wave][(k / GROUP_G) * 8 + my_g];
             // LDS float add into the plane this wave shares with ONE other wave: every (entry, term) receives at most
             // one add per wave, and a + b == b + a, so the result does not depend on which wave arrives first
-            if (my_idx < GROUP_G * NPART && myj >= 0)
+            if (my_idx < GROUP_G * NPART && myj < BATCH)
                 __hip_atomic_fetch_add(&s_part[wave >> 1][myj][my_c], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
