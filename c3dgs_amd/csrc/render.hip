@@ -123,8 +123,9 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
 {
     const int tile = tile_of_block(blockIdx.x, T);
     if (tile >= T || (blockIdx.x >> 3) >= ((T + 7) >> 3)) return;
-    __shared__ float4 s_a[2][BATCH + 1];             // entry BATCH of each buffer: sentinel with opacity 0 (blends nothing)
-    __shared__ float4 s_b[2][BATCH + 1];
+    // a and b halves of an entry side by side: one address register serves both reads (the buffer index is a run-time
+    // value, so two arrays would need two). Entry BATCH of each buffer: sentinel with opacity 0 (blends nothing)
+    __shared__ float4 s_ab[2][BATCH + 1][2];
     __shared__ float s_c[2][BATCH + 1];
     __shared__ uint16_t s_list[4][(BATCH / 8 + 2) * 8];   // per wave: its candidates of the batch, 8 per 16-byte row
     __shared__ int s_wdone[2][4];
@@ -139,7 +140,7 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     const float pxf = (float)px, pyf = (float)py;
     bool done = !inside;
     if (tid == 0) s_used = 0;
-    if (tid < 2) { s_a[tid][BATCH] = make_float4(0, 0, 0, 0); s_b[tid][BATCH] = make_float4(0, 0, 0, 0); s_c[tid][BATCH] = 0.f; }
+    if (tid < 2) { s_ab[tid][BATCH][0] = make_float4(0, 0, 0, 0); s_ab[tid][BATCH][1] = make_float4(0, 0, 0, 0); s_c[tid][BATCH] = 0.f; }
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
     const uint2 range = ranges[tile];
@@ -156,7 +157,7 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     }
     for (int r = 0; r < rounds; r++) {
         const int buf = r & 1;
-        s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc.x;
+        s_ab[buf][tid][0] = ra; s_ab[buf][tid][1] = rb; s_c[buf][tid] = rc.x;
         const uint32_t qm = (r * BATCH + tid < n) ? quadrant_mask(ra, rb, tile_x0, tile_y0) : 0u;
         if (r * BATCH + tid < n) qmask[range.x + r * BATCH + tid] = (uint8_t)qm;   // the backward reuses it (same test, ~100 VALU ops)
 #pragma unroll
@@ -201,7 +202,7 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
 #pragma unroll
             for (int g = 0; g < 8; g++) {
                 const int j = (int)((rw[g >> 1] >> ((g & 1) * 16)) & 0xffffu);
-                const float4 a = s_a[buf][j], b = s_b[buf][j];
+                const float4 a = s_ab[buf][j][0], b = s_ab[buf][j][1];
                 const float cblue = s_c[buf][j];
                 float dx, dy, G, alpha;
                 const bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
