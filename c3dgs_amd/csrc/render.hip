@@ -34,10 +34,11 @@ __device__ __forceinline__ bool gaussian_alpha(float mx, float my, float ca, flo
     dx = mx - pxf;
     dy = my - pyf;
     const float power = fmaf(-0.5f, fmaf(ca, dx * dx, cc * (dy * dy)), -(cb * (dx * dy)));
-    if (power > 0.0f) return false;
+    // no early return: G and alpha are always written (callers select on the result anyway), which saves the compiler
+    // a select per call; for power > 0 they hold values nobody uses
     G = __expf(power);
     alpha = fminf(0.99f, op * G);
-    return !(alpha < 1.0f / 255.0f);
+    return !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
 }
 
 // Which of the tile's four 8x8 quadrants (= waves) can this Gaussian touch at all?  A pixel only blends the
@@ -210,7 +211,7 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
                 const bool live_px = hit && !done;
                 const float test_T = Tr * (1.f - alpha);
                 const bool stop = live_px && test_T < 0.0001f;   // forward.cu:355-360: stop BEFORE blending this one
-                const bool blend = live_px && !stop;
+                const bool blend = live_px != stop;              // stop implies live_px: one mask xor, no second compare
                 const float w = blend ? alpha * Tr : 0.f;
                 C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(cblue, w, C2);
                 Tr = blend ? test_T : Tr;
