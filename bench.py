@@ -460,8 +460,7 @@ def bench_vq(c3dgs_amd, _lib, dev, rank, world, steps):
         lo, hi = (rank * B) // world, ((rank + 1) * B) // world
         _, S, dsum = model.partial_sums(feats, imp, gather=b[lo:hi].contiguous())
         if world > 1:
-            dist.all_reduce(S)
-            dist.all_reduce(dsum)
+            S, dsum = vqm.all_reduce_sums(dist, None, S, dsum)
         model.apply_sums(S)
 
     for b in batches[:2]:
