@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 GRAD_TOL = 1e-4
 
 
-def _check_forward(hipo, st):
+def _check_forward(hipo, st, borderline_ok=False):
     assert hipo["num_rendered"] == st.num_rendered
     np.testing.assert_array_equal(hipo["radii"], st.radii)
     if st.P > 0:
@@ -49,11 +49,21 @@ def _check_forward(hipo, st):
     rng = np.random.default_rng(5)
     target = rng.random(a.shape, dtype=np.float32)
     assert abs(gpu_util.psnr(a, target) - gpu_util.psnr(b, target)) <= 0.05
-    np.testing.assert_allclose(a, b, atol=2e-5, rtol=1e-4)
+    if borderline_ok:
+        # deep blend lists (thousands of splats per pixel): an exp() ulp may flip one alpha >= 1/255 / T < 1e-4 decision at a
+        # pixel, which moves it by at most one borderline contribution (alpha T c <= 1/255); everything else stays tight
+        bad = np.abs(a - b) > 2e-5 + 1e-4 * np.abs(b)
+        assert bad.mean() <= 1e-4 and np.abs(a - b).max() <= 4e-3, (bad.sum(), np.abs(a - b).max())
+    else:
+        np.testing.assert_allclose(a, b, atol=2e-5, rtol=1e-4)
     # per-pixel bookkeeping: identical except where an exp() ulp flips a threshold (expected: almost never)
     same = (hipo["n_contrib"] == st.n_contrib).mean()
     assert same >= 0.999, f"n_contrib agreement {same}"
-    np.testing.assert_allclose(hipo["final_T"], st.final_T, atol=1e-5, rtol=1e-4)
+    if borderline_ok:
+        dT = np.abs(hipo["final_T"] - st.final_T)
+        assert (dT > 1e-5 + 1e-4 * np.abs(st.final_T)).mean() <= 1e-4 and dT.max() <= 4e-3
+    else:
+        np.testing.assert_allclose(hipo["final_T"], st.final_T, atol=1e-5, rtol=1e-4)
 
 
 @pytest.mark.parametrize("name", cases.FORWARD_CASES)
