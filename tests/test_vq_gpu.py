@@ -165,3 +165,43 @@ def test_vq_features_default_draws_equal_explicit_batches(hip):
     torch.manual_seed(78)
     cb_c, _ = hip.vq_features(f, imp, K, chunk, steps, init_rand=init, silent=True, scale_normalize=True)
     assert not torch.allclose(cb_a, cb_c, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_weighted_distance_random_shapes_and_near_ties(hip, orc, seed):
+    """Random N, C, K (MFMA widths 6 / 12 / 48 and others, C below and above the MFMA path's minimum, ragged tiles), with
+    the things that stress the exactness logic mixed in: duplicated and nearly duplicated codewords, points sitting on
+    codewords and on midpoints between two of them, large offsets (||x|| >> distances), a gather. Bit-exact."""
+    r = np.random.default_rng(seed)
+    K = int(r.choice([6, 12, 48, 48, 6, int(r.integers(1, 65))]))
+    C = int(r.choice([1, 31, 32, 33, 127, 128, 129, 4096, int(r.integers(2, 3000))]))
+    N = int(r.choice([1, 63, 64, 65, 255, 257, int(r.integers(2, 20000))]))
+    g = torch.Generator().manual_seed(seed)
+    scale = float(np.exp(r.uniform(np.log(1e-3), np.log(10.0))))
+    offset = float(r.choice([0.0, 0.0, 5.0, 100.0])) * scale
+    cb = torch.randn(C, K, generator=g) * scale + offset
+    if C > 4:
+        nd = max(1, C // 8)
+        src = torch.randint(0, C, (nd,), generator=g)
+        dst = torch.randint(0, C, (nd,), generator=g)
+        cb[dst] = cb[src]                                               # exact duplicates: lowest index must win
+        dst2 = torch.randint(0, C, (nd,), generator=g)
+        cb[dst2] = cb[src] * (1 + 1e-7) + 1e-9 * scale                  # near duplicates: inside the ambiguity window
+    x = torch.randn(N, K, generator=g) * scale + offset
+    if N > 8:
+        x[::5] = cb[torch.randint(0, C, (len(x[::5]),), generator=g)]   # points on codewords (distance 0)
+        i, j = torch.randint(0, C, (2, len(x[1::7])), generator=g)
+        x[1::7] = 0.5 * (cb[i] + cb[j])                                 # midpoints: two exactly (or almost) equal distances
+    x, cb = x.float().contiguous(), cb.float().contiguous()
+    gather = None
+    if r.random() < 0.4 and N > 1:
+        gather = torch.randint(0, N, (N,), generator=g)
+    d_ref, i_ref = orc.weighted_distance(x.numpy() if gather is None else x[gather].numpy(), cb.numpy())
+    if gather is None:
+        d, i = hip.weightedDistance(x.cuda(), cb.cuda())
+    else:
+        from c3dgs_amd.vq import weightedDistance
+        d, i = weightedDistance(x.cuda(), cb.cuda(), gather.cuda())
+    what = f"seed {seed}: N={N} C={C} K={K} scale={scale:.3g} offset={offset:.3g} gather={gather is not None}"
+    np.testing.assert_array_equal(i.cpu().numpy(), i_ref, err_msg=what)
+    np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), d_ref.view(np.uint32), err_msg=what)
