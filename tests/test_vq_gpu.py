@@ -137,6 +137,15 @@ def test_batch_draws_on_device_equal_the_cpu_generator_stream(hip):
     for a, b in zip(ref, got):
         assert b.dtype == torch.int64 and torch.equal(a, b.cpu())
     assert torch.equal(torch.rand(4), after)
+    # a loop that stops early: the batch drawn ahead is taken back, torch continues as after 5 reference draws
+    torch.manual_seed(22)
+    ref5 = [torch.randint(low=0, high=N, size=[chunk]) for _ in range(5)]
+    after5 = torch.rand(4)
+    torch.manual_seed(22)
+    d = _BatchDraws(N, chunk, steps, torch.device("cuda", 0))
+    got5 = [d.next_batch() for _ in range(5)]
+    d.finish()
+    assert all(torch.equal(a, b.cpu()) for a, b in zip(ref5, got5)) and torch.equal(torch.rand(4), after5)
 
 
 def test_vq_features_default_draws_equal_explicit_batches(hip):
