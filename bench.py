@@ -456,9 +456,11 @@ def bench_vq(c3dgs_amd, _lib, dev, rank, world, steps):
     cpu_g = torch.Generator().manual_seed(11)
     batches = [torch.randint(0, N, (B,), generator=cpu_g).to(dev) for _ in range(steps + 2)]
 
+    scratch = {}
+
     def one(b):
         lo, hi = (rank * B) // world, ((rank + 1) * B) // world
-        _, S, dsum = model.partial_sums(feats, imp, gather=b[lo:hi].contiguous())
+        _, S, dsum = model.partial_sums(feats, imp, gather=b[lo:hi].contiguous(), scratch=scratch)
         if world > 1:
             S, dsum = vqm.all_reduce_sums(dist, None, S, dsum)
         model.apply_sums(S)

@@ -420,6 +420,20 @@ int c3dgs_vq_accumulate(int64_t B, int32_t K, int32_t D, const float* x, const f
     return C3DGS_OK;
 }
 
+int c3dgs_vq_sums(int64_t B, int32_t K, int32_t D, const float* x, const float* w, const int64_t* gather,
+                  const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, void* stream)
+{
+    if (B < 0 || K <= 0 || D <= 0) return fail(C3DGS_E_INVALID, "bad sizes");
+    if (!S || !dist_sum) return fail(C3DGS_E_INVALID, "S and dist_sum are required");
+    C3DGS_HIP_TRY(hipMemsetAsync(S, 0, (size_t)K * (D + 1) * sizeof(float), (hipStream_t)stream));
+    C3DGS_HIP_TRY(hipMemsetAsync(dist_sum, 0, sizeof(double), (hipStream_t)stream));
+    if (B == 0) return C3DGS_OK;
+    if (!x || !w || !codebook || !dist || !idx) return fail(C3DGS_E_INVALID, "x, w, codebook, dist and idx are required");
+    const int rc = c3dgs_weighted_distance(B, K, D, x, gather, codebook, dist, idx, stream);
+    if (rc != C3DGS_OK) return rc;
+    return c3dgs_vq_accumulate(B, K, D, x, w, gather, idx, dist, S, dist_sum, stream);
+}
+
 int c3dgs_vq_apply(int32_t K, int32_t D, const float* S, float* codebook, float* entry_importance, float decay,
                    float alpha, float eps, int32_t scale_normalize, void* stream)
 {

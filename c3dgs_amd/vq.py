@@ -86,6 +86,36 @@ class HipOps:
         return S, dsum
 
     @staticmethod
+    def sums(x, importance, gather, codebook, scratch=None):
+        """assign + accumulate as one library call (no intermediate tensors, no zero-fill launches). `scratch`: a dict
+        that keeps the per-batch buffers (distances, indices, S) alive across steps of one loop; None allocates fresh.
+        -> (min_dists f32[B], S f32[K, D+1], dist_sum f64[1])."""
+        L = _lib.lib()
+        K, D = int(codebook.shape[0]), int(x.size(1))
+        B = int(gather.numel()) if gather is not None else int(x.size(0))
+        dev = x.device
+        key = (B, K, D, dev)
+        bufs = scratch.get(key) if scratch is not None else None
+        if bufs is None:
+            bufs = (torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.int64, device=dev),
+                    torch.empty(K, D + 1, dtype=torch.float32, device=dev))
+            if scratch is not None:
+                scratch.clear()
+                scratch[key] = bufs
+        dist, idx, S = bufs
+        dsum = torch.empty(1, dtype=torch.float64, device=dev)
+        xw = x.detach().contiguous().float()
+        w = importance.detach().contiguous().float()
+        cb = codebook.detach().contiguous().float()
+        if gather is not None:
+            gather = gather.to(device=dev, dtype=torch.int64).contiguous()
+        with torch.cuda.device(dev):
+            rc = L.c3dgs_vq_sums(B, K, D, xw.data_ptr(), w.data_ptr(), gather.data_ptr() if gather is not None else None,
+                                 cb.data_ptr(), dist.data_ptr(), idx.data_ptr(), S.data_ptr(), dsum.data_ptr(), _stream(dev))
+        _lib.check(rc)
+        return dist, S, dsum
+
+    @staticmethod
     def apply(S, codebook, entry_importance, decay, eps, scale_normalize):
         L = _lib.lib()
         K, D = codebook.shape
@@ -113,9 +143,12 @@ class VectorQuantize(nn.Module):
         r = torch.rand_like(self.codebook) if rand is None else rand.to(self.codebook)
         self.codebook.data = r * (amax - amin) + amin
 
-    def partial_sums(self, x: torch.Tensor, importance: torch.Tensor, gather: Optional[torch.Tensor] = None):
+    def partial_sums(self, x: torch.Tensor, importance: torch.Tensor, gather: Optional[torch.Tensor] = None, scratch=None):
         """Assignment + weighted scatter-sums of one (slice of a) batch.
-        Returns (min_dists f32[B], S f32[K, D+1] = [sum w*x | sum w], dist_sum f64[1])."""
+        Returns (min_dists f32[B], S f32[K, D+1] = [sum w*x | sum w], dist_sum f64[1]). With `scratch` (a dict owned by the
+        calling loop) min_dists and S are reused from step to step."""
+        if hasattr(self.ops, "sums") and x.is_cuda:
+            return self.ops.sums(x, importance, gather, self.codebook.data, scratch)
         min_dists, idx = self.ops.assign(x, self.codebook.data, gather)
         S, dsum = self.ops.accumulate(x, importance, gather, idx, min_dists, int(self.codebook.shape[0]))
         return min_dists, S, dsum
@@ -249,6 +282,7 @@ def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size:
     feats = features.detach().contiguous().float()
     imp = importance_n.detach().contiguous().float()
     err_sums = []
+    scratch = {}
     it = range(steps) if batches is None else range(len(batches))
     draws = None if batches is not None else _BatchDraws(N, vq_chunk, steps, dev, device_rng)
     try:
@@ -262,7 +296,7 @@ def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size:
             B = int(batch.numel())
             lo, hi = (rank * B) // world, ((rank + 1) * B) // world
             with torch.no_grad():
-                _, S, dsum = vq_model.partial_sums(feats, imp, gather=batch[lo:hi].contiguous())
+                _, S, dsum = vq_model.partial_sums(feats, imp, gather=batch[lo:hi].contiguous(), scratch=scratch)
                 if world > 1:
                     S, dsum = all_reduce_sums(dist, pg, S, dsum)
                 vq_model.apply_sums(S, scale_normalize=scale_normalize)

@@ -136,6 +136,11 @@ int c3dgs_vq_accumulate(int64_t B, int32_t K, int32_t D, const float* x, const f
                         const int64_t* gather /*NULL, or row n of x and w is [gather[n]]*/,
                         const int64_t* idx, const float* dist, float* S, double* dist_sum, void* stream);
 
+/* sums: the first half of a Lloyd step in ONE call -- clears S and *dist_sum, assigns the B (gathered) rows
+ * (== c3dgs_weighted_distance into dist / idx) and accumulates them (== c3dgs_vq_accumulate). */
+int c3dgs_vq_sums(int64_t B, int32_t K, int32_t D, const float* x, const float* w, const int64_t* gather,
+                  const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, void* stream);
+
 /* apply: entry_importance = decay*entry_importance + alpha*S[:,D];
  *        codebook = decay*codebook + alpha * S[:, :D] / (S[:,D] + eps)        (ema_inplace, vq.py:45-46)
  * then, if scale_normalize (D>=6): codebook /= (cb[:,0]+cb[:,3]+cb[:,5])[:,None]   (vq.py:73-77). */
