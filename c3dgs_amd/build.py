@@ -24,7 +24,7 @@ SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "backward_preprocess.hip": ["-ffp-contract=off"] + os.environ.get("C3DGS_BWDPRE_FLAGS", "").split(),
     "binning.hip": [],
-    "radix_sort.hip": [],
+    "radix_sort.hip": os.environ.get("C3DGS_SORT_FLAGS", "").split(),
     # SLP packing into v_pk_*_f32 costs register shuffles in the blend loops and keeps DPP adds from fusing
     "render.hip": os.environ.get("C3DGS_RENDER_FLAGS", "-fno-slp-vectorize").split(),
     "vq.hip": [],

@@ -24,10 +24,20 @@
 
 namespace c3dgs {
 
-constexpr int OS_TILE = 8192, OS_RADIX = 256;
-// tile shape per key width (measured): u16 keys 1024 threads x 8 items, u32 keys 512 x 16 (82 KB of LDS would allow only one
-// 1024-thread workgroup per CU)
-template <class K> struct OsShape { static constexpr int BLOCK = sizeof(K) == 2 ? 1024 : 512; static constexpr int IPT = OS_TILE / BLOCK; };
+constexpr int OS_RADIX = 256;
+// tile shape per key width (measured): u16 keys 8192-item tiles, 1024 threads x 8 items; u32 keys C3DGS_OS_TILE32 items with
+// C3DGS_OS_BLOCK32 threads (82 KB of LDS would allow only one 1024-thread workgroup per CU)
+#ifndef C3DGS_OS_TILE32
+#define C3DGS_OS_TILE32 8192
+#endif
+#ifndef C3DGS_OS_BLOCK32
+#define C3DGS_OS_BLOCK32 512
+#endif
+template <class K> struct OsShape {
+    static constexpr int TILE = sizeof(K) == 2 ? 8192 : C3DGS_OS_TILE32;
+    static constexpr int BLOCK = sizeof(K) == 2 ? 1024 : C3DGS_OS_BLOCK32;
+    static constexpr int IPT = TILE / BLOCK;
+};
 constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_PRE = 2u << 30, OS_CNT_MASK = (1u << 30) - 1;
 constexpr int OS_MAX_PASSES = 4;
 // every look-back spin is bounded (a predecessor's word normally arrives within microseconds); on time-out the pass
@@ -51,10 +61,10 @@ static OsPlan os_plan(int total_bits)
     return p;
 }
 
-static size_t os_blocks(size_t n) { return (n + OS_TILE - 1) / OS_TILE; }
-static size_t os_ctrl_bytes(size_t n, int passes)
+template <class K> static size_t os_blocks(size_t n) { return (n + OsShape<K>::TILE - 1) / OsShape<K>::TILE; }
+template <class K> static size_t os_ctrl_bytes(size_t n, int passes)
 {
-    return align_up(((size_t)passes * OS_RADIX + (size_t)passes * os_blocks(n) * OS_RADIX + 64) * sizeof(uint32_t));
+    return align_up(((size_t)passes * OS_RADIX + (size_t)passes * os_blocks<K>(n) * OS_RADIX + 64) * sizeof(uint32_t));
 }
 
 // all digit histograms in one read of the keys: 1024-thread workgroups (at most 512 of them, so the final flush stays a
@@ -115,6 +125,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
     __shared__ int32_t s_gbase[OS_RADIX];            // global position = s_gbase[digit] + tile-sorted position
     __shared__ uint32_t s_wtot[4];
     __shared__ uint32_t s_bid;
+    constexpr int OS_TILE = OsShape<K>::TILE;
     __shared__ K s_keys[OS_TILE];
     __shared__ uint32_t s_vals[OS_TILE];
 
@@ -249,7 +260,7 @@ template <class K>
 static size_t os_temp_bytes(size_t n, int total_bits)
 {
     const OsPlan plan = os_plan(total_bits);
-    size_t b = os_ctrl_bytes(n, plan.passes);
+    size_t b = os_ctrl_bytes<K>(n, plan.passes);
     const int bufs = plan.passes >= 3 ? 2 : (plan.passes == 2 ? 1 : 0);
     b += (size_t)bufs * (align_up(n * sizeof(K)) + align_up(n * sizeof(uint32_t)));
     return b;
@@ -262,9 +273,9 @@ static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, 
     if (n == 0) return hipSuccess;
     if (n >= ((size_t)1 << 30) || os_temp_bytes<K>(n, total_bits) > temp_bytes) return hipErrorInvalidValue;
     const OsPlan plan = os_plan(total_bits);
-    const size_t blocks = os_blocks(n);
+    const size_t blocks = os_blocks<K>(n);
     char* base = (char*)temp;
-    const size_t ctrl = os_ctrl_bytes(n, plan.passes);
+    const size_t ctrl = os_ctrl_bytes<K>(n, plan.passes);
     uint32_t* hist = (uint32_t*)base;
     uint32_t* status = hist + (size_t)plan.passes * OS_RADIX;
     uint32_t* ticket = status + (size_t)plan.passes * blocks * OS_RADIX;
@@ -296,7 +307,9 @@ int onesweep_timed_out(const void* temp, size_t n, int total_bits, hipStream_t s
 {
     if (!onesweep_enabled() || n == 0 || n >= ((size_t)1 << 30)) return 0;
     const OsPlan plan = os_plan(total_bits);
-    const uint32_t* ticket = (const uint32_t*)temp + (size_t)plan.passes * OS_RADIX + (size_t)plan.passes * os_blocks(n) * OS_RADIX;
+    // the depth sort (32 bits) runs on u32 keys, the tile sort (<= 16 bits) on u16 keys: their tile sizes may differ
+    const size_t nblocks = total_bits > 16 ? os_blocks<uint32_t>(n) : os_blocks<uint16_t>(n);
+    const uint32_t* ticket = (const uint32_t*)temp + (size_t)plan.passes * OS_RADIX + (size_t)plan.passes * nblocks * OS_RADIX;
     uint32_t w[OS_MAX_PASSES] = { 0, 0, 0, 0 };
     if (hipMemcpyAsync(w, ticket + OS_ERR_WORD, sizeof(w), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
     if (hipStreamSynchronize(s) != hipSuccess) return 1;
