@@ -14,6 +14,10 @@ Extra objects on the same JSON line:
   cpu_baseline  the oracle (CPU restatement, OpenMP) timed on this box's host cores on a bounded sample
   stages        per-stage mean ms from the same HIP events (all kernels of the view)
   vq            sensitivity-weighted VQ Lloyd steps/s on config 4's colour shape, sharded over the N ranks (RCCL)
+  (N = 1 only)  qat_loop: the step + fused L1/SSIM loss; qat_model: the whole QAT view / iteration from raw parameters (fused
+                glue + fused Adam next to the reference's torch glue + torch Adam); postvq_index_layout: the headline step with
+                the codebook indices laid out as compression/vq.py's join_features produces them
+  device_allocs_in_timed_region   hipMalloc calls of torch's caching allocator during the K timed steps (expected 0)
 """
 import argparse
 import json
