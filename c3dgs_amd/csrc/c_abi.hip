@@ -409,6 +409,22 @@ int c3dgs_weighted_distance(int64_t N, int32_t C, int32_t K, const float* coefs,
     return C3DGS_OK;
 }
 
+int c3dgs_weighted_distance_ws(int64_t N, int32_t C, int32_t K, const float* coefs, const int64_t* gather, const float* codebook,
+                               float* out_dist, int64_t* out_idx, int32_t* flag_ws, int32_t flag_cap, void* stream)
+{
+    if (N < 0 || C < 0 || K <= 0) return fail(C3DGS_E_INVALID, "coefs and codebook must have same number of channels");
+    if (N == 0) return C3DGS_OK;
+    if (!coefs || !codebook || !out_dist || !out_idx) return fail(C3DGS_E_INVALID, "ceofs and codebook must have dimension 2");
+    {
+        StageTimer t_(ST_WDIST, (hipStream_t)stream);
+        if (launch_weighted_distance(N, C, K, coefs, gather, codebook, out_dist, out_idx, (hipStream_t)stream, flag_ws,
+                                     flag_ws ? flag_cap : 0))
+            return fail(C3DGS_E_INVALID, "unsupported channel count");
+    }
+    C3DGS_STAGE("weighted_distance", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
 int c3dgs_vq_accumulate(int64_t B, int32_t K, int32_t D, const float* x, const float* w, const int64_t* gather,
                         const int64_t* idx, const float* dist, float* S, double* dist_sum, void* stream)
 {
@@ -421,7 +437,8 @@ int c3dgs_vq_accumulate(int64_t B, int32_t K, int32_t D, const float* x, const f
 }
 
 int c3dgs_vq_sums(int64_t B, int32_t K, int32_t D, const float* x, const float* w, const int64_t* gather,
-                  const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, void* stream)
+                  const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, int32_t* flag_ws,
+                  int32_t flag_cap, void* stream)
 {
     if (B < 0 || K <= 0 || D <= 0) return fail(C3DGS_E_INVALID, "bad sizes");
     if (!S || !dist_sum) return fail(C3DGS_E_INVALID, "S and dist_sum are required");
@@ -429,8 +446,12 @@ int c3dgs_vq_sums(int64_t B, int32_t K, int32_t D, const float* x, const float* 
     C3DGS_HIP_TRY(hipMemsetAsync(dist_sum, 0, sizeof(double), (hipStream_t)stream));
     if (B == 0) return C3DGS_OK;
     if (!x || !w || !codebook || !dist || !idx) return fail(C3DGS_E_INVALID, "x, w, codebook, dist and idx are required");
-    const int rc = c3dgs_weighted_distance(B, K, D, x, gather, codebook, dist, idx, stream);
-    if (rc != C3DGS_OK) return rc;
+    {
+        StageTimer t_(ST_WDIST, (hipStream_t)stream);
+        if (launch_weighted_distance(B, K, D, x, gather, codebook, dist, idx, (hipStream_t)stream, flag_ws, flag_ws ? flag_cap : 0))
+            return fail(C3DGS_E_INVALID, "unsupported channel count");
+    }
+    C3DGS_STAGE("weighted_distance", 0, (hipStream_t)stream);
     return c3dgs_vq_accumulate(B, K, D, x, w, gather, idx, dist, S, dist_sum, stream);
 }
 

@@ -9,6 +9,7 @@
 // memory per thread; here a 256-thread workgroup keeps its points in registers (2 per lane) and
 // streams the codebook through LDS in tiles that every lane reads as a broadcast.
 #include "common.hpp"
+#include <algorithm>
 #include <cfloat>
 #include <cstdlib>
 
@@ -148,7 +149,8 @@ __device__ __forceinline__ void top2_update(float v, int row, float& best, float
 template <int MF_K>
 __global__ void __launch_bounds__(256)
 wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather,
-               const float* __restrict__ codebook, float* __restrict__ out_dist, int64_t* __restrict__ out_idx)
+               const float* __restrict__ codebook, float* __restrict__ out_dist, int64_t* __restrict__ out_idx,
+               int* __restrict__ flag_list, int flag_cap)
 {
     static_assert(MF_K % 2 == 0, "two dims per v_mfma_f32_32x32x2_f32 step");
     __shared__ float s_cb[2][MF_K][MF_CT];   // k-major tile: lane i reads s_cb[k][i] (consecutive banks)
@@ -266,6 +268,10 @@ wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
             }
             out_dist[n] = r;
             out_idx[n] = ambiguous ? (int64_t)-1 : (int64_t)ni;
+            if (ambiguous && flag_list) {             // optional list of the flagged points: [0] = count, then the points
+                const int pos = atomicAdd(&flag_list[0], 1);
+                if (pos < flag_cap) flag_list[1 + pos] = (int)n;
+            }
         }
     }
 }
@@ -327,8 +333,98 @@ wd_fixup_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t
     }
 }
 
+// exact re-scan of LISTED flagged points, WD_FB of them per codebook pass: the cost of a re-scan is reading the codebook
+// (786 KB from L2 for K = 4096 x 48), so a workgroup loads every codeword row once into registers and runs the k-ordered
+// FMA chain against WD_FB points whose rows sit in LDS (broadcast reads). Same result as wd_fixup_kernel (which still runs
+// afterwards and picks up whatever did not fit the list).
+constexpr int WD_FB = 4;
+template <int K>
+__global__ void __launch_bounds__(256)
+wd_fixup_list_kernel(int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather, const float* __restrict__ codebook,
+                     float* __restrict__ out_dist, int64_t* __restrict__ out_idx, const int* __restrict__ flag_list, int flag_cap)
+{
+    __shared__ float s_x[WD_FB][K];
+    __shared__ float s_best[WD_FB][4];
+    __shared__ int s_besti[WD_FB][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int count = min(flag_list[0], flag_cap);
+    for (int base = (int)blockIdx.x * WD_FB; base < count; base += (int)gridDim.x * WD_FB) {
+        const int np = min(WD_FB, count - base);
+        __syncthreads();                                             // previous group's LDS has been read
+        for (int q = tid; q < WD_FB * K; q += 256) {
+            const int p = q / K, k = q - p * K;
+            float v = 0.f;
+            if (p < np) {
+                const int64_t n = flag_list[1 + base + p];
+                v = coefs[(gather ? gather[n] : n) * K + k];
+            }
+            s_x[p][k] = v;
+        }
+        __syncthreads();
+        float best[WD_FB];
+        int besti[WD_FB];
+#pragma unroll
+        for (int p = 0; p < WD_FB; p++) { best[p] = FLT_MAX; besti[p] = 0x7fffffff; }
+        for (int c = tid; c < C; c += 256) {
+            float cb[K];
+            const float* src = codebook + (size_t)c * K;
+#pragma unroll
+            for (int k = 0; k < K; k++) cb[k] = src[k];
+#pragma unroll
+            for (int p = 0; p < WD_FB; p++) {
+                float r = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const float d = s_x[p][k] - cb[k];
+                    r = fmaf(d, d, r);
+                }
+                if (r < best[p]) { best[p] = r; besti[p] = c; }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < WD_FB; p++) {
+            float b = best[p];
+            int bi = besti[p];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(b, o);
+                const int oi = __shfl_xor(bi, o);
+                if (ob < b || (ob == b && oi < bi)) { b = ob; bi = oi; }
+            }
+            if (lane == 0) { s_best[p][wave] = b; s_besti[p][wave] = bi; }
+        }
+        __syncthreads();
+        if (tid < np) {
+            float b = s_best[tid][0];
+            int bi = s_besti[tid][0];
+#pragma unroll
+            for (int w = 1; w < 4; w++)
+                if (s_best[tid][w] < b || (s_best[tid][w] == b && s_besti[tid][w] < bi)) { b = s_best[tid][w]; bi = s_besti[tid][w]; }
+            const int64_t n = flag_list[1 + base + tid];
+            out_dist[n] = b;
+            out_idx[n] = (int64_t)(bi == 0x7fffffff ? 0 : bi);
+        }
+    }
+}
+
+template <int K>
+static void launch_wd_mfma(int64_t N, int C, const float* coefs, const int64_t* gather, const float* codebook, float* out_dist,
+                           int64_t* out_idx, int* flag_list, int flag_cap, hipStream_t s)
+{
+    const unsigned g1 = (unsigned)((N + 4 * MF_PTS - 1) / (4 * MF_PTS)), g2 = (unsigned)((N + 63) / 64);
+    if (flag_list && flag_cap > 0 && N < ((int64_t)1 << 31)) {
+        (void)hipMemsetAsync(flag_list, 0, sizeof(int), s);
+        wd_mfma_kernel<K><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
+        const unsigned gl = (unsigned)std::min<int64_t>(1024, (flag_cap + WD_FB - 1) / WD_FB);
+        wd_fixup_list_kernel<K><<<gl, 256, 0, s>>>(C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
+    } else {
+        wd_mfma_kernel<K><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, nullptr, 0);
+    }
+    wd_fixup_kernel<K><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);   // whatever is still flagged
+}
+
 int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const int64_t* gather, const float* codebook,
-                             float* out_dist, int64_t* out_idx, hipStream_t s)
+                             float* out_dist, int64_t* out_idx, hipStream_t s, int* flag_list, int flag_cap)
 {
     if (N <= 0) return 0;
     const int64_t per_block = (int64_t)WD_BLOCK * WD_PPT;
@@ -336,17 +432,10 @@ int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const 
     const bool al16 = (((uintptr_t)coefs | (uintptr_t)codebook) & 15) == 0;
     const bool al8 = (((uintptr_t)coefs | (uintptr_t)codebook) & 7) == 0;
     static const bool force_exact = getenv("C3DGS_VQ_EXACT_VALU") != nullptr;   // A/B switch for tests and profiling
-    const unsigned g1 = (unsigned)((N + 4 * MF_PTS - 1) / (4 * MF_PTS)), g2 = (unsigned)((N + 63) / 64);
-    if (K == 48 && al16 && C >= 32 && !force_exact) {
-        wd_mfma_kernel<48><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
-        wd_fixup_kernel<48><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
-    } else if (K == 12 && al8 && C >= 32 && !force_exact) {
-        wd_mfma_kernel<12><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
-        wd_fixup_kernel<12><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
-    } else if (K == 6 && al8 && C >= 32 && !force_exact) {
-        wd_mfma_kernel<6><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
-        wd_fixup_kernel<6><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
-    } else if (K == 48 && al16) weighted_distance_kernel<48, 128><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
+    if (K == 48 && al16 && C >= 32 && !force_exact) launch_wd_mfma<48>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap, s);
+    else if (K == 12 && al8 && C >= 32 && !force_exact) launch_wd_mfma<12>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap, s);
+    else if (K == 6 && al8 && C >= 32 && !force_exact) launch_wd_mfma<6>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap, s);
+    else if (K == 48 && al16) weighted_distance_kernel<48, 128><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
     else if (K == 12 && al16) weighted_distance_kernel<12, 512><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
     else if (K == 6 && al8) weighted_distance_kernel<6, 1024><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
     else {

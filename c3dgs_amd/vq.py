@@ -47,9 +47,11 @@ def weightedDistance(coefs: torch.Tensor, codebook: torch.Tensor, gather: Option
     idx = torch.zeros(N, dtype=torch.int64, device=x.device)
     if N > 0 and cb.size(0) > 0:
         with torch.cuda.device(x.device):
-            rc = L.c3dgs_weighted_distance(N, int(cb.size(0)), int(x.size(1)), x.data_ptr(),
-                                           gather.data_ptr() if gather is not None else None, cb.data_ptr(),
-                                           dist.data_ptr(), idx.data_ptr(), _stream(x.device))
+            flags = torch.empty(N // 8 + 2, dtype=torch.int32, device=x.device)     # list of ambiguous points (typically ~1 %)
+            rc = L.c3dgs_weighted_distance_ws(N, int(cb.size(0)), int(x.size(1)), x.data_ptr(),
+                                              gather.data_ptr() if gather is not None else None, cb.data_ptr(),
+                                              dist.data_ptr(), idx.data_ptr(), flags.data_ptr(), int(flags.numel()) - 1,
+                                              _stream(x.device))
         _lib.check(rc)
     return dist, idx
 
@@ -98,11 +100,12 @@ class HipOps:
         bufs = scratch.get(key) if scratch is not None else None
         if bufs is None:
             bufs = (torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.int64, device=dev),
-                    torch.empty(K, D + 1, dtype=torch.float32, device=dev))
+                    torch.empty(K, D + 1, dtype=torch.float32, device=dev),
+                    torch.empty(B // 8 + 2, dtype=torch.int32, device=dev))        # list of ambiguous points (typically ~1 %)
             if scratch is not None:
                 scratch.clear()
                 scratch[key] = bufs
-        dist, idx, S = bufs
+        dist, idx, S, flags = bufs
         dsum = torch.empty(1, dtype=torch.float64, device=dev)
         xw = x.detach().contiguous().float()
         w = importance.detach().contiguous().float()
@@ -111,7 +114,8 @@ class HipOps:
             gather = gather.to(device=dev, dtype=torch.int64).contiguous()
         with torch.cuda.device(dev):
             rc = L.c3dgs_vq_sums(B, K, D, xw.data_ptr(), w.data_ptr(), gather.data_ptr() if gather is not None else None,
-                                 cb.data_ptr(), dist.data_ptr(), idx.data_ptr(), S.data_ptr(), dsum.data_ptr(), _stream(dev))
+                                 cb.data_ptr(), dist.data_ptr(), idx.data_ptr(), S.data_ptr(), dsum.data_ptr(),
+                                 flags.data_ptr(), int(flags.numel()) - 1, _stream(dev))
         _lib.check(rc)
         return dist, S, dsum
 

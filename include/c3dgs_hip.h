@@ -129,6 +129,12 @@ int c3dgs_rasterize_gaussians_backward_indexed(const c3dgs_raster_params* p, con
 int c3dgs_weighted_distance(int64_t N, int32_t C, int32_t K, const float* coefs, const int64_t* gather,
                             const float* codebook, float* out_dist, int64_t* out_idx, void* stream);
 
+/* the same with device scratch (int32[flag_cap + 1]) for the list of ambiguous points, which are then re-scanned several
+ * per codebook pass instead of one by one; identical results */
+int c3dgs_weighted_distance_ws(int64_t N, int32_t C, int32_t K, const float* coefs, const int64_t* gather,
+                               const float* codebook, float* out_dist, int64_t* out_idx, int32_t* flag_ws, int32_t flag_cap,
+                               void* stream);
+
 /* ---- VectorQuantize.update, split at the point where a sharded run all-reduces (compression/vq.py:28-35) ----
  * accumulate: S[k, 0..D) += w_n * x_n ; S[k, D] += w_n for k = idx[n];  *dist_sum += sum_n dist[n] (may be NULL).
  * S [K, D+1] fp32 must be zeroed by the caller (it is the all-reduce payload). */
@@ -137,9 +143,12 @@ int c3dgs_vq_accumulate(int64_t B, int32_t K, int32_t D, const float* x, const f
                         const int64_t* idx, const float* dist, float* S, double* dist_sum, void* stream);
 
 /* sums: the first half of a Lloyd step in ONE call -- clears S and *dist_sum, assigns the B (gathered) rows
- * (== c3dgs_weighted_distance into dist / idx) and accumulates them (== c3dgs_vq_accumulate). */
+ * (== c3dgs_weighted_distance into dist / idx) and accumulates them (== c3dgs_vq_accumulate).
+ * flag_ws (optional, int32[flag_cap + 1] device scratch): lets the assignment list the points whose two best candidates
+ * are too close to call from the fast search and re-scan them several per codebook pass; same results without it. */
 int c3dgs_vq_sums(int64_t B, int32_t K, int32_t D, const float* x, const float* w, const int64_t* gather,
-                  const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, void* stream);
+                  const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, int32_t* flag_ws,
+                  int32_t flag_cap, void* stream);
 
 /* apply: entry_importance = decay*entry_importance + alpha*S[:,D];
  *        codebook = decay*codebook + alpha * S[:, :D] / (S[:,D] + eps)        (ema_inplace, vq.py:45-46)
