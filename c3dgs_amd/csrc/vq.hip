@@ -136,14 +136,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MF_CT = 128;          // codewords per LDS tile
 constexpr int MF_PTS = 64;          // points per wave (two 32-point B operands)
 
-// 4 VALU operations per distance: with best <= second the new second smallest of {v, best, second} is their median
-// (v < best: best; best <= v < second: v; otherwise second), one v_med3_f32 instead of a max and a min. The update is
-// what the search kernel spends its VALU time on (a top-3 variant with 10 operations ran 14-50 % slower).
-__device__ __forceinline__ void top2_update(float v, int row, float& best, float& second, int& idx)
+// 3 VALU operations per distance. (1) The accumulator row (0..15) is written into the 4 low mantissa bits of the value
+// (one v_and_or_b32), so the running minimum carries its own row and needs no compare + select; which 32-codeword group
+// it came from is noted once per sub-tile. The values move by < 16 ulp = 1.9e-6 relative, which the ambiguity margin
+// (4e-5, against a rigorous need of ~2.6e-5) covers -- a wrong pick can only happen inside the window,
+// and everything inside the window is re-decided exactly. (2) With best <= second the new second smallest of
+// {v, best, second} is their median: one v_med3_f32. The update is what the search kernel spends its VALU time on
+// (a top-3 variant with 10 operations ran 14-50 % slower).
+__device__ __forceinline__ void top2_update(float v, uint32_t code, uint32_t keep_mask, float& best, float& second)
 {
-    second = __builtin_amdgcn_fmed3f(v, best, second);
-    idx = v < best ? row : idx;
-    best = fminf(v, best);
+    const float vp = __uint_as_float((__float_as_uint(v) & keep_mask) | code);
+    second = __builtin_amdgcn_fmed3f(vp, best, second);
+    best = fminf(vp, best);
 }
 
 template <int MF_K>
@@ -181,7 +185,8 @@ wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
         xnorm[g] = part;
     }
     float best[2] = { FLT_MAX, FLT_MAX }, second[2] = { FLT_MAX, FLT_MAX };
-    int idx[2] = { 0, 0 };
+    int grp[2] = { 0, 0 };                           // 32-codeword group of the current best (its row: low 4 bits of best)
+    const uint32_t keep_mask = 0xfffffff0u;
 
     const int ntiles = (C + MF_CT - 1) / MF_CT;
     auto stage = [&](int tile, int buf) {
@@ -235,24 +240,29 @@ wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[0][t], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[1][t], acc1, 0, 0, 0);
             }
-            const int row0 = tile * MF_CT + sub * 32 + 4 * h;
+            const float was0 = best[0], was1 = best[1];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int row = row0 + (r & 3) + 8 * (r >> 2);
-                top2_update(acc0[r], row, best[0], second[0], idx[0]);
-                top2_update(acc1[r], row, best[1], second[1], idx[1]);
+                top2_update(acc0[r], (uint32_t)r, keep_mask, best[0], second[0]);
+                top2_update(acc1[r], (uint32_t)r, keep_mask, best[1], second[1]);
             }
+            const int gid = tile * (MF_CT / 32) + sub;
+            grp[0] = best[0] < was0 ? gid : grp[0];
+            grp[1] = best[1] < was1 ? gid : grp[1];
         }
         __syncthreads();
     }
     // merge the two half-waves (same point in lanes l and l^32), decide, recompute the exact distance
 #pragma unroll
     for (int g = 0; g < 2; g++) {
+        // accumulator row r of lane half h in group G is codeword 32 G + (r & 3) + 8 (r >> 2) + 4 h
+        const int code = (int)(__float_as_uint(best[g]) & 15u);
+        const int my_idx = grp[g] * 32 + (code & 3) + 8 * (code >> 2) + 4 * h;
         const float ob = __shfl_xor(best[g], 32), os = __shfl_xor(second[g], 32);
-        const int oi = __shfl_xor(idx[g], 32);
+        const int oi = __shfl_xor(my_idx, 32);
         const float nb = fminf(best[g], ob);
         const float ns = fminf(fminf(second[g], os), fmaxf(best[g], ob));
-        const int ni = (ob < best[g] || (ob == best[g] && oi < idx[g])) ? oi : idx[g];
+        const int ni = (ob < best[g] || (ob == best[g] && oi < my_idx)) ? oi : my_idx;
         const int64_t n = n_base + 32 * g + i;
         if (h == 0 && n < N) {
             const float db = nb + xnorm[g], ds = ns + xnorm[g];
