@@ -184,7 +184,10 @@ wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
         }
         xnorm[g] = part;
     }
-    float best[2] = { FLT_MAX, FLT_MAX }, second[2] = { FLT_MAX, FLT_MAX };
+    // start value: FLT_MAX with the row bits clear, so a point that never finds a smaller value (all-NaN input) decodes to
+    // codeword 0 like the reference's `min_idx = 0` start
+    const float big = __uint_as_float(0x7f7ffff0u);
+    float best[2] = { big, big }, second[2] = { FLT_MAX, FLT_MAX };
     int grp[2] = { 0, 0 };                           // 32-codeword group of the current best (its row: low 4 bits of best)
     const uint32_t keep_mask = 0xfffffff0u;
 

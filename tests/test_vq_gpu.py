@@ -214,3 +214,15 @@ def test_weighted_distance_random_shapes_and_near_ties(hip, orc, seed):
     what = f"seed {seed}: N={N} C={C} K={K} scale={scale:.3g} offset={offset:.3g} gather={gather is not None}"
     np.testing.assert_array_equal(i.cpu().numpy(), i_ref, err_msg=what)
     np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), d_ref.view(np.uint32), err_msg=what)
+
+
+def test_weighted_distance_nan_rows_fall_back_to_codeword_zero(hip):
+    """A query row of NaNs compares false against everything: like the reference's `if (d < min_dist)` it keeps index 0."""
+    x, cb = _data(300, 512, 48, seed=9)
+    x[7] = float("nan")
+    x[200, 3] = float("nan")
+    d, i = hip.weightedDistance(x.cuda(), cb.cuda())
+    assert int(i[7]) == 0 and int(i[200]) == 0
+    ok = torch.ones(300, dtype=torch.bool); ok[7] = ok[200] = False
+    d2, i2 = hip.weightedDistance(x[ok].cuda(), cb.cuda())
+    assert torch.equal(i[ok.cuda()], i2) and torch.equal(d[ok.cuda()], d2)
