@@ -147,6 +147,39 @@ def test_full_hd_properties(hip):
     assert np.abs(g["dL_dmeans3D"]).max() > 0
 
 
+def test_4k_image_properties(hip):
+    """3840x2160 (32,400 tiles: 15 tile-id bits, two uneven digit passes of the tile sort) with the indexed path: the same
+    size-independent properties, and the per-Gaussian gradients that involve no float atomics are bitwise reproducible."""
+    W, H, focal, P = 3840, 2160, 2400.0, 600_000
+    intr, ev = synth.camera(W, H, focal)
+    from oracle import oracle as o
+    cam = o.camera(intr.numpy(), ev.numpy())
+    sc = synth.scene(P, W, H, focal, seed=77, scale_median=0.012)
+    ix = synth.index_scene(sc, seed=78)
+    inp = dict(bg=torch.zeros(3), means3D=ix["means3D"], opacities=ix["opacities"], shs=ix["shs"], scales=ix["scales"],
+               rotations=ix["rotations"], scale_factors=ix["scale_factors"], sh_indices=ix["sh_indices"],
+               g_indices=ix["g_indices"], degree=3, clamp_color=True)
+    fw = gpu_util.hip_forward(inp, cam, True)
+    u = gpu_util.unpack(fw)
+    R = u["num_rendered"]
+    assert R == int(u["tiles_touched"].astype(np.int64).sum()) and R > P
+    ks = u["keys_sorted"]
+    assert np.all(ks[1:] >= ks[:-1]) and int(ks[-1] >> np.uint64(32)) > 2 ** 14          # the 15th tile bit is in use
+    order = np.lexsort((u["values_unsorted"], u["keys_unsorted"]))
+    np.testing.assert_array_equal(u["values_unsorted"][order], u["point_list"])
+    rg = u["ranges"].astype(np.int64)
+    cnt = np.bincount((ks >> np.uint64(32)).astype(np.int64), minlength=rg.shape[0])
+    np.testing.assert_array_equal(rg[:, 1] - rg[:, 0], cnt)
+    assert ((u["final_T"] >= 0) & (u["final_T"] <= 1)).all() and np.isfinite(u["out_color"]).all()
+    g = gpu_util.hip_backward(fw, synth.grad_image(W, H).numpy())
+    for k, v in g.items():
+        assert np.isfinite(v).all(), k
+    assert np.abs(g["dL_dmeans3D"]).max() > 0
+    g2 = gpu_util.hip_backward(fw, synth.grad_image(W, H).numpy())
+    for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscale_factors"):                         # no float atomics on these
+        np.testing.assert_array_equal(g[k].view(np.uint32), g2[k].view(np.uint32))
+
+
 def test_debug_and_prefiltered_flags(hip, orc):
     """debug=True synchronises after every stage (reference CHECK_CUDA) and changes no result; prefiltered=True skips
     the near-plane test (auxiliary.h:146-147), which is a no-op on a scene that is entirely in front of the camera."""
