@@ -59,3 +59,19 @@ def test_sort_of_already_sorted_and_constant_keys():
     asc = (torch.arange(n, device="cuda") * 8160 // n).to(torch.int16)
     ko, vo = _sort(asc, vals, 13)
     assert torch.equal(vo, vals) and torch.equal(ko, asc)
+
+
+def test_rocprim_fallback_gives_the_same_sorted_lists():
+    """C3DGS_SORT_ROCPRIM=1 (also taken automatically from 2^30 items on) routes both sorts through rocPRIM: the raster
+    parity cases that compare the sorted keys / point list bit-exactly must pass unchanged. Run in a child process
+    because the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, C3DGS_SORT_ROCPRIM="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_raster_gpu.py", "tests/test_sort_gpu.py", "-q", "-m", "gpu", "-x",
+                        "-k", "(forward_parity and (base or wide_depth or p8193 or equal_depth or indexed)) or ragged or stable_sort"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
