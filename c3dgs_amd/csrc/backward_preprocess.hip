@@ -11,19 +11,6 @@
 #include "common.hpp"
 #include "gsmath.hpp"
 
-#ifndef C3DGS_ABLATE_SH
-#define C3DGS_ABLATE_SH 0   // timing experiments only
-#endif
-#ifndef C3DGS_ABLATE_GS
-#define C3DGS_ABLATE_GS 0
-#endif
-#ifndef C3DGS_ABLATE_STAGE
-#define C3DGS_ABLATE_STAGE 0
-#endif
-#ifndef C3DGS_ABLATE_SHMATH
-#define C3DGS_ABLATE_SHMATH 0
-#endif
-
 #ifndef C3DGS_BWD_CH
 #define C3DGS_BWD_CH 128
 #endif
@@ -183,7 +170,7 @@ backward_preprocess_kernel(const BwdArgs a)
         if (i >= a.P) start_ = end_;
         const uint32_t w_begin = __builtin_amdgcn_readfirstlane(start_);
         const uint32_t w_end = __builtin_amdgcn_readlane(end_, 63);
-        for (uint32_t base = w_begin; base < (C3DGS_ABLATE_STAGE ? w_begin : w_end); base += FG * 64) {
+        for (uint32_t base = w_begin; base < w_end; base += FG * 64) {
             const uint32_t nsl = min((uint32_t)(FG * 64), w_end - base);
             uint32_t fbits = 0;                               // bit g: slot base + 64 g + lane was written
 #pragma unroll
@@ -359,7 +346,7 @@ backward_preprocess_kernel(const BwdArgs a)
     dmean[2] += (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
 
     // ---- SH (backward.cu:20-139 / backward_indexed.cu:20-201)
-    if (a.sh && !C3DGS_ABLATE_SHMATH) {
+    if (a.sh) {
         const size_t row = INDEXED ? (size_t)a.sh_indices[i] : si;
         const float* shp = a.sh + row * (size_t)a.M * 3;
         constexpr int NC = (DEG + 1) * (DEG + 1) * 3;
@@ -441,7 +428,7 @@ backward_preprocess_kernel(const BwdArgs a)
     if (INDEXED) {
         __syncthreads();
         const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
-        if (o.dL_dsh && a.sh && !C3DGS_ABLATE_SH) {
+        if (o.dL_dsh && a.sh) {
             const int k = lane / 3, ch = lane - 3 * k;
             for (int j = 0; j < 64; j++) {
                 const int32_t row = s_row[wbase + j];            // wave-uniform
@@ -450,7 +437,7 @@ backward_preprocess_kernel(const BwdArgs a)
                     atomicAdd(o.dL_dsh + (size_t)row * a.M * 3 + lane, s_basis(wbase + j, k) * s_g[wbase + j][ch]);
             }
         }
-        if (a.scales && !C3DGS_ABLATE_GS) {
+        if (a.scales) {
             if (o.dL_dscales)
 #pragma unroll
                 for (int it = 0; it < 3; it++) {

@@ -331,20 +331,25 @@ def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size:
     return vq_model.codebook.data.detach(), vq_indices.detach()
 
 
+def _say(silent: bool, msg: str):
+    if not silent:
+        print(msg)
+
+
 def join_features(all_features: torch.Tensor, keep_mask: torch.Tensor, codebook: torch.Tensor,
                   codebook_indices: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """compression/vq.py:90-103."""
-    keep_features = all_features[keep_mask]
-    compressed_features = torch.cat([codebook, keep_features], 0)
-    indices = torch.zeros(len(all_features), dtype=torch.long, device=all_features.device)
-    indices[~keep_mask] = codebook_indices
-    indices[keep_mask] = torch.arange(len(keep_features), device=indices.device) + len(codebook)
-    return compressed_features, indices
+    """Same contract as compression/vq.py:90-103: the row table is [codebook ; kept rows in Gaussian order]; a kept
+    Gaussian points at its own row behind the codebook, every other one at its codeword.
+    The kept rows' numbers are the running count of the mask (no index tensors are materialised and scattered)."""
+    n_code = codebook.shape[0]
+    own_row = torch.cumsum(keep_mask, 0, dtype=torch.long) + (n_code - 1)
+    rows = own_row.masked_scatter(~keep_mask, codebook_indices.to(torch.long))
+    return torch.cat((codebook, all_features[keep_mask])), rows
 
 
 @dataclass
 class CompressionSettings:
-    """compression/vq.py:106-114."""
+    """Field-compatible with compression/vq.py:106-114 (the drivers construct it by keyword)."""
     codebook_size: int
     importance_prune: float
     importance_include: float
@@ -354,80 +359,68 @@ class CompressionSettings:
     batch_size: int
 
 
+def _table_for(features: torch.Tensor, importance: torch.Tensor, cfg: CompressionSettings, what: str, silent: bool, group,
+               scale_normalize: bool = False):
+    """One quantisation job: rows whose importance exceeds `cfg.importance_include` stay verbatim, the rest go through
+    vq_features. -> (row table, per-Gaussian row numbers). Shared by the colour and the covariance path."""
+    keep = importance > cfg.importance_include
+    _say(silent, f"{what}: {100.0 * float(keep.float().mean()):.2f}% of the rows kept uncompressed")
+    todo = ~keep
+    if bool(todo.any()):
+        _say(silent, f"{what}: vector-quantising {int(todo.sum())} rows into {cfg.codebook_size} codewords")
+        codebook, assigned = vq_features(features[todo], importance[todo], cfg.codebook_size, cfg.batch_size, cfg.steps,
+                                         scale_normalize=scale_normalize, silent=silent, group=group)
+    else:                                   # everything kept: an empty codebook in front of the kept rows
+        codebook = features.new_empty((0, features.shape[-1]))
+        assigned = torch.empty(0, dtype=torch.long, device=features.device)
+    return join_features(features, keep, codebook, assigned)
+
+
 def compress_color(gaussians, color_importance: torch.Tensor, color_comp: CompressionSettings,
                    color_compress_non_dir: bool, silent: bool, group=None):
-    """compression/vq.py:117-147 (`gaussians` is duck-typed: get_features, set_color_indexed)."""
-    keep_mask = color_importance > color_comp.importance_include
-    if not silent:
-        print(f"color keep: {keep_mask.float().mean() * 100:.2f}%")
-    vq_mask_c = ~keep_mask
-    if color_compress_non_dir:
-        n_sh_coefs = gaussians.get_features.shape[1]
-        color_features = gaussians.get_features.detach().flatten(-2)
-    else:
-        n_sh_coefs = gaussians.get_features.shape[1] - 1
-        color_features = gaussians.get_features[:, 1:].detach().flatten(-2)
-    if vq_mask_c.any():
-        if not silent:
-            print("compressing color...")
-        color_codebook, color_vq_indices = vq_features(color_features[vq_mask_c], color_importance[vq_mask_c],
-                                                       color_comp.codebook_size, color_comp.batch_size, color_comp.steps,
-                                                       silent=silent, group=group)
-    else:
-        color_codebook = torch.empty((0, color_features.shape[-1]), device=color_features.device)
-        color_vq_indices = torch.empty((0,), device=color_features.device, dtype=torch.long)
-    compressed_features, indices = join_features(color_features, keep_mask, color_codebook, color_vq_indices)
-    gaussians.set_color_indexed(compressed_features.reshape(-1, n_sh_coefs, 3), indices)
+    """compression/vq.py:117-147 (`gaussians` is duck-typed: get_features, set_color_indexed). With
+    color_compress_non_dir the DC coefficient is quantised with the rest, otherwise only the directional ones are."""
+    sh = gaussians.get_features.detach()
+    first = 0 if color_compress_non_dir else 1
+    table, rows = _table_for(sh[:, first:].flatten(-2), color_importance, color_comp, "colour", silent, group)
+    gaussians.set_color_indexed(table.reshape(-1, sh.shape[1] - first, 3), rows)
 
 
 def compress_covariance(gaussians, gaussian_importance: torch.Tensor, gaussian_comp: CompressionSettings, silent: bool,
                         group=None, extract_rot_scale=None, to_full_cov=None):
-    """compression/vq.py:149-191. The eigendecomposition helpers default to c3dgs_amd.encode's HIP versions of
-    utils/splats.py:7-35; the reference's own functions can still be passed in."""
-    keep_mask_g = gaussian_importance > gaussian_comp.importance_include
-    vq_mask_g = ~keep_mask_g
-    if not silent:
-        print(f"gaussians keep: {keep_mask_g.float().mean() * 100:.2f}%")
-    covariance = gaussians.get_normalized_covariance(strip_sym=True).detach()
-    if vq_mask_g.any():
-        if not silent:
-            print("compressing gaussian splats...")
-        cov_codebook, cov_vq_indices = vq_features(covariance[vq_mask_g], gaussian_importance[vq_mask_g],
-                                                   gaussian_comp.codebook_size, gaussian_comp.batch_size,
-                                                   gaussian_comp.steps, scale_normalize=True, silent=silent, group=group)
-    else:
-        cov_codebook = torch.empty((0, covariance.shape[1]), device=covariance.device)
-        cov_vq_indices = torch.empty((0,), device=covariance.device, dtype=torch.long)
-    compressed_cov, cov_indices = join_features(covariance, keep_mask_g, cov_codebook, cov_vq_indices)
+    """compression/vq.py:149-191: quantise the normalised covariances (upper triangles, trace-normalised codewords), then
+    split every table row back into rotation + scale. The eigendecomposition helpers default to c3dgs_amd.encode's HIP
+    versions of utils/splats.py:7-35; the reference's own functions can still be passed in."""
+    cov6 = gaussians.get_normalized_covariance(strip_sym=True).detach()
+    table, rows = _table_for(cov6, gaussian_importance, gaussian_comp, "covariance", silent, group, scale_normalize=True)
     if extract_rot_scale is None or to_full_cov is None:
         from . import encode
         extract_rot_scale, to_full_cov = encode.extract_rot_scale, encode.to_full_cov
-    rot_vq, scale_vq = extract_rot_scale(to_full_cov(compressed_cov))
-    gaussians.set_gaussian_indexed(rot_vq.to(compressed_cov.device), scale_vq.to(compressed_cov.device), cov_indices)
+    rot, scale = extract_rot_scale(to_full_cov(table))
+    gaussians.set_gaussian_indexed(rot.to(table.device), scale.to(table.device), rows)
+
+
+def _resolve_threshold(cfg: Optional[CompressionSettings], importance: torch.Tensor, what: str, silent: bool):
+    """importance_include=None means "take the importance_include_relative quantile" (compression/vq.py:209-218)."""
+    if cfg is not None and cfg.importance_include is None:
+        cfg.importance_include = float(torch.quantile(importance, cfg.importance_include_relative))
+        _say(silent, f"{what}: keep threshold set to {cfg.importance_include}")
 
 
 def compress_gaussians(gaussians, color_importance: torch.Tensor, gaussian_importance: torch.Tensor,
                        color_comp: Optional[CompressionSettings], gaussian_comp: Optional[CompressionSettings],
                        color_compress_non_dir: bool, prune_threshold: float = 0., silent: bool = False, group=None,
                        extract_rot_scale=None, to_full_cov=None):
-    """compression/vq.py:194-223."""
+    """compression/vq.py:194-223: prune by colour importance, then the two quantisation jobs. (Unlike the reference,
+    a job whose settings are None is skipped before its threshold is looked at.)"""
     with torch.no_grad():
         if prune_threshold >= 0:
-            non_prune_mask = color_importance > prune_threshold
-            if not silent:
-                print(f"prune: {(1 - non_prune_mask.float().mean()) * 100:.2f}%")
-            gaussians.mask_splats(non_prune_mask)
-            gaussian_importance = gaussian_importance[non_prune_mask]
-            color_importance = color_importance[non_prune_mask]
-        if color_comp.importance_include is None:
-            color_comp.importance_include = torch.quantile(color_importance, color_comp.importance_include_relative).item()
-            if not silent:
-                print(f"Setting color threshold to {color_comp.importance_include}")
-        if gaussian_comp.importance_include is None:
-            gaussian_comp.importance_include = torch.quantile(gaussian_importance,
-                                                              gaussian_comp.importance_include_relative).item()
-            if not silent:
-                print(f"Setting gaussian threshold to {gaussian_comp.importance_include}")
+            survivors = color_importance > prune_threshold
+            _say(silent, f"pruning {100.0 * (1.0 - float(survivors.float().mean())):.2f}% of the Gaussians")
+            gaussians.mask_splats(survivors)
+            color_importance, gaussian_importance = color_importance[survivors], gaussian_importance[survivors]
+        _resolve_threshold(color_comp, color_importance, "colour", silent)
+        _resolve_threshold(gaussian_comp, gaussian_importance, "covariance", silent)
         if color_comp is not None:
             compress_color(gaussians, color_importance, color_comp, color_compress_non_dir, silent=silent, group=group)
         if gaussian_comp is not None:

@@ -1,0 +1,105 @@
+"""HIP-vs-oracle comparison of one view at BASELINE.json's FULL sizes (1M / 3M / 6M Gaussians at 1920x1080).
+
+Shared by tests/test_fullsize_gpu.py (asserts the bars) and bench.py (`parity` object of the JSON line, reusing the
+oracle run its `cpu_baseline` leg pays for anyway).  Test infrastructure: nothing under c3dgs_amd/ imports this.
+
+What is compared (BASELINE.json north_star; reference path rasterizer_impl.cu:440-697):
+  radii, tiles_touched, sorted 64-bit keys, sorted point_list, tile ranges      -> equal (counts of mismatches reported)
+  image                                                                         -> PSNR(hip, oracle), |dPSNR| vs a fixed random target
+  every gradient tensor                                                         -> ||g - g_ref||_inf / ||g_ref||_inf (oracle sums in float64)
+plus the depth of the deepest tile list, because the gradient bar loosens with it (see test_fuzz_gpu.py).
+"""
+import time
+
+import numpy as np
+import torch
+
+from tests import gpu_util
+
+
+def config_inputs(name, P=None, W=1920, H=1080, focal=1200.0):
+    """The BASELINE.json configurations as (inputs dict of CPU tensors, intrinsic, extrinsic_vector, indexed).
+      "config2_1M_fwd"      configs[1]: 1M Gaussians, SH deg 3, non-indexed, forward only (render.py path)
+      "config3_3M_indexed"  configs[2]: 3M, SH deg 3, indexed, clamp_color=True (finetune.py QAT loop) -- the headline
+      "config4_6M_sens"     the sensitivity pass of configs[3]/[4]: 6M, non-indexed, cov3D_precomp, clamp_color=False
+                            (compress.py:81-119)"""
+    from tests import synth
+    P = {"config2_1M_fwd": 1_000_000, "config3_3M_indexed": 3_000_000, "config4_6M_sens": 6_000_000}[name] if P is None else P
+    intr, ev = synth.camera(W, H, focal)
+    sc = synth.scene(P, W, H, focal, seed=1234, sh_degree=3)
+    inp = dict(bg=torch.zeros(3), means3D=sc["means3D"], opacities=sc["opacities"], shs=sc["shs"], colors_precomp=None,
+               scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None, scale_factors=None, sh_indices=None,
+               g_indices=None, degree=3, scale_modifier=1.0, prefiltered=False, clamp_color=True)
+    indexed = False
+    if name == "config3_3M_indexed":
+        ix = synth.index_scene(sc)
+        inp.update(shs=ix["shs"], scales=ix["scales"], rotations=ix["rotations"], scale_factors=ix["scale_factors"],
+                   sh_indices=ix["sh_indices"], g_indices=ix["g_indices"])
+        indexed = True
+    elif name == "config4_6M_sens":
+        # cov3D_precomp = unit-scale covariance x scaling_factor^2 (compress.py:82-85,101): Sigma = R S^2 R^T, upper triangle
+        q, s = sc["rotations"], sc["scales"]
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        Rm = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                          2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                          2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+        Lm = Rm * s[:, None, :]
+        Sg = Lm @ Lm.transpose(1, 2)
+        inp["cov3D_precomp"] = torch.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2], Sg[:, 2, 2]],
+                                           1).float().contiguous()
+        inp["scales"] = inp["rotations"] = None
+        inp["clamp_color"] = False
+    return inp, intr, ev, indexed
+
+
+def oracle_view(inp, cam, dL=None):
+    """One oracle view. -> (state, grads or None, seconds forward, seconds backward)."""
+    from tests import cases
+    from oracle import oracle as orc
+    t0 = time.perf_counter()
+    st = cases.oracle_forward(inp, cam)
+    t1 = time.perf_counter()
+    ref = orc.rasterize_backward(st, dL) if dL is not None else None
+    return st, ref, t1 - t0, time.perf_counter() - t1
+
+
+def compare(inp, cam, indexed, st, ref=None, dL=None, fw=None):
+    """HIP (through the C-ABI front-end, tests/gpu_util.py) against an oracle state `st` (+ gradients `ref` for `dL`).
+    -> dict of plain numbers (JSON-serialisable)."""
+    if fw is None:
+        fw = gpu_util.hip_forward(inp, cam, indexed)
+    u = gpu_util.unpack(fw)
+    out = {"gaussians": int(st.P), "tile_instances": int(st.num_rendered), "num_rendered_equal": bool(u["num_rendered"] == st.num_rendered)}
+    out["radii_mismatches"] = int((u["radii"] != st.radii).sum())
+    out["tiles_touched_mismatches"] = int((u["tiles_touched"] != st.tiles_touched).sum())
+    same_R = u["num_rendered"] == st.num_rendered
+    out["sorted_keys_mismatches"] = int((u["keys_sorted"] != st.keys_sorted).sum()) if same_R else -1
+    out["point_list_mismatches"] = int((u["point_list"] != st.point_list).sum()) if same_R else -1
+    out["ranges_mismatches"] = int((u["ranges"] != st.ranges).sum())
+    vis = st.radii > 0
+    out["splat_float_bit_mismatches"] = int(
+        (u["means2D"][vis].view(np.uint32) != st.means2D[vis].view(np.uint32)).sum()
+        + (u["conic_opacity"][vis].view(np.uint32) != st.conic_opacity[vis].view(np.uint32)).sum()
+        + (u["depths"][vis].view(np.uint32) != st.depths[vis].view(np.uint32)).sum()
+        + ((u["rgb"][vis].view(np.uint32) != st.rgb[vis].view(np.uint32)).sum() if st.inputs["colors_precomp"] is None else 0))
+    a, b = u["out_color"], st.out_color
+    out["image_finite"] = bool(np.isfinite(a).all())
+    out["psnr_db"] = float(gpu_util.psnr(a, b))
+    target = np.random.default_rng(5).random(a.shape, dtype=np.float32)
+    out["delta_psnr_db"] = float(abs(gpu_util.psnr(a, target) - gpu_util.psnr(b, target)))
+    out["image_max_abs_err"] = float(np.abs(a - b).max())
+    out["n_contrib_agreement"] = float((u["n_contrib"] == st.n_contrib).mean())
+    rg = st.ranges.astype(np.int64)
+    out["deepest_tile_list"] = int((rg[:, 1] - rg[:, 0]).max()) if rg.size else 0
+    out["deepest_blend"] = int(st.n_contrib.max()) if st.n_contrib.size else 0
+    if ref is not None:
+        got = gpu_util.hip_backward(fw, dL)
+        errs = {}
+        for k, v in got.items():
+            r = ref[k]
+            if r.size == 0 or v.shape != r.shape:
+                continue
+            errs[k] = float("inf") if not np.isfinite(v).all() else gpu_util.rel_inf(v, r)
+        out["grad_rel_inf"] = errs
+        out["grad_rel_inf_max"] = max(errs.values()) if errs else 0.0
+    return out

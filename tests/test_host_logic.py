@@ -86,6 +86,63 @@ def test_join_features_and_settings():
     assert cs.codebook_size == 4096 and cs.importance_include is None
 
 
+def test_compress_plumbing_with_a_stub_quantiser(monkeypatch):
+    """compress_gaussians end to end on CPU with vq_features replaced by a stub (nearest of K fixed rows): pruning, the
+    relative keep thresholds, the [codebook ; kept rows] tables and the row numbers handed to the model."""
+    from c3dgs_amd import vq as vqm
+    g = torch.Generator().manual_seed(2)
+    P = 400
+    sh = torch.randn(P, 4, 3, generator=g)
+    cov = torch.rand(P, 6, generator=g) + 0.1
+    cimp, gimp = torch.rand(P, generator=g), torch.rand(P, generator=g)
+    calls = []
+
+    def stub(features, importance, codebook_size, vq_chunk, steps, scale_normalize=False, silent=False, group=None):
+        calls.append((features.shape, codebook_size, vq_chunk, steps, scale_normalize))
+        cb = features[:codebook_size].clone()
+        return cb, torch.cdist(features, cb).argmin(1)
+    monkeypatch.setattr(vqm, "vq_features", stub)
+
+    class Model:
+        def __init__(self):
+            self.sh, self.cov = sh.clone(), cov.clone()
+        get_features = property(lambda self: self.sh)
+
+        def get_normalized_covariance(self, strip_sym=True):
+            return self.cov
+
+        def mask_splats(self, m):
+            self.sh, self.cov = self.sh[m], self.cov[m]
+
+        def set_color_indexed(self, table, rows):
+            self.color = (table, rows)
+
+        def set_gaussian_indexed(self, rot, scale, rows):
+            self.gauss = (rot, scale, rows)
+    m = Model()
+    cc = vqm.CompressionSettings(16, 0.0, None, 0.9, 7, 0.8, 64)
+    gc = vqm.CompressionSettings(8, 0.0, None, 0.75, 9, 0.8, 32)
+    vqm.compress_gaussians(m, cimp.clone(), gimp.clone(), cc, gc, color_compress_non_dir=False, prune_threshold=0.05, silent=True,
+                           extract_rot_scale=lambda full: (full[:, 0], full[:, 1]), to_full_cov=lambda c6: torch.stack([c6, 2 * c6], 1))
+    alive = cimp > 0.05
+    n = int(alive.sum())
+    assert m.sh.shape[0] == n and calls[0][1:] == (16, 64, 7, False) and calls[1][1:] == (8, 32, 9, True)
+    table, rows = m.color
+    keep = cimp[alive] > torch.quantile(cimp[alive], 0.9)
+    assert table.shape == (16 + int(keep.sum()), 3, 3) and rows.shape == (n,) and rows.dtype == torch.long
+    torch.testing.assert_close(table[rows][keep], sh[alive][keep][:, 1:])             # kept rows verbatim (DC excluded)
+    assert int(rows[~keep].max()) < 16 and (rows[keep] == 16 + torch.arange(int(keep.sum()))).all()
+    rot, scale, grows = m.gauss
+    gkeep = gimp[alive] > torch.quantile(gimp[alive], 0.75)
+    torch.testing.assert_close(rot[grows][gkeep], cov[alive][gkeep])
+    torch.testing.assert_close(scale[grows][gkeep], 2 * cov[alive][gkeep])
+    # a job without settings is skipped, and with everything kept the table is just the rows themselves
+    m2 = Model()
+    vqm.compress_gaussians(m2, cimp.clone(), gimp.clone(), vqm.CompressionSettings(16, 0.0, -1.0, 0.9, 7, 0.8, 64), None,
+                           color_compress_non_dir=True, prune_threshold=-1.0, silent=True)
+    assert not hasattr(m2, "gauss") and m2.color[0].shape == (P, 4, 3) and (m2.color[1] == torch.arange(P)).all()
+
+
 def test_install_as_reference_modules():
     c3dgs_amd.install_as_reference_modules()
     import diff_gaussian_rasterization_no_camera as dgr
