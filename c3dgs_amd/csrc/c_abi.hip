@@ -130,7 +130,9 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     const GeomPtrs g = geom_ptrs(geom_base, P);
 
     // K2 / K2i, with the id-order scan of tiles_touched folded in (per-workgroup offsets + block_base[])
-    { StageTimer t_(ST_PREPROCESS, s); launch_preprocess(p, g, radii, img.ranges, s); }
+    uint32_t* sort_err = onesweep_error_word();
+    if (!sort_err) return fail(C3DGS_E_HIP, "cannot resolve the sort error word");
+    { StageTimer t_(ST_PREPROCESS, s); launch_preprocess(p, g, radii, img.ranges, sort_err, s); }
     C3DGS_STAGE("preprocess", p.debug, s);
     // The one device->host read of the forward (K4, num_rendered) is issued as EARLY as its value exists: R is the last
     // entry of block_base[]. The copy lands in pinned memory behind an event while the depth sort and the depth-order
@@ -138,13 +140,14 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     // rest (the reference blocks the stream at this point, rasterizer_impl.cu:279).
     HostRead& hr = host_read();
     if (!hr.pinned) return fail(C3DGS_E_HIP, "pinned host buffer allocation failed");
-    C3DGS_HIP_TRY(hipMemcpyAsync(hr.pinned, g.block_base + (P + 255) / 256, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    // second word: the device's sticky sort time-out flag as of the start of this call (radix_sort.hip)
+    C3DGS_HIP_TRY(hipMemcpyAsync(hr.pinned, g.block_base + (P + 255) / 256, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     C3DGS_HIP_TRY(hipEventRecord(hr.ev, s));
     { StageTimer t_(ST_DEPTH_SORT, s);                                               // binning stage 1: P Gaussians by depth
       C3DGS_HIP_TRY(run_depth_sort(g.scan_temp, g.scan_temp_bytes, g.depth_keys, g.depth_keys_sorted, g.ids, g.depth_order, P,
                                    reinterpret_cast<const uint2*>(g.rects), g.sorted_offsets, s)); }
     C3DGS_STAGE("depth_sort", p.debug, s);
-    if (p.debug && onesweep_timed_out(g.scan_temp, (size_t)P, 32, s)) return fail(C3DGS_E_HIP, "depth sort: look-back timed out");
+    if (p.debug && onesweep_timed_out(s)) return fail(C3DGS_E_HIP, "depth sort: look-back timed out");
     { StageTimer t_(ST_SCAN, s); launch_depth_order_scan(P, g, s); }                 // K3, in depth order (two-level)
     C3DGS_STAGE("scan", p.debug, s);
     // Poll instead of sleeping in the driver: on a busy host the wake-up from a blocking event wait can take
@@ -155,7 +158,14 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
         if (q == hipErrorNotReady) q = hipEventSynchronize(hr.ev);
         if (q != hipSuccess) return fail(C3DGS_E_HIP, std::string("num_rendered read: ") + hipGetErrorString(q));
     }
-    const uint32_t R_u = *hr.pinned;
+    const uint32_t R_u = hr.pinned[0];
+    if (hr.pinned[1] != 0) {
+        // A radix-sort look-back timed out in an EARLIER rasterizer call on this device (that call's image was poisoned with
+        // NaN by render_forward). Not silent outside debug mode: fail here, at the forward's one natural host read.
+        C3DGS_HIP_TRY(hipMemsetAsync(sort_err, 0, sizeof(uint32_t), s));
+        return fail(C3DGS_E_HIP, "radix sort look-back timed out in an earlier rasterizer call on this device: that call's "
+                                 "image is NaN and its gradients are invalid (flag cleared, this call was not run)");
+    }
     if (R_u > 0x7fffffffu) return fail(C3DGS_E_INVALID, "num_rendered overflows int32");
     const int R = (int)R_u;
     *num_rendered = R;
@@ -173,13 +183,13 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
           C3DGS_HIP_TRY(run_tile_sort(b.sort_temp, b.sort_temp_bytes, b.keys_unsorted, b.keys_sorted, b.values_unsorted,
                                       b.point_list, R, end_bit, s)); }               // K6, binning stage 2
         C3DGS_STAGE("sort", p.debug, s);
-        if (p.debug && onesweep_timed_out(b.sort_temp, (size_t)R, end_bit, s)) return fail(C3DGS_E_HIP, "tile sort: look-back timed out");
+        if (p.debug && onesweep_timed_out(s)) return fail(C3DGS_E_HIP, "tile sort: look-back timed out");
         { StageTimer t_(ST_RANGES, s); launch_identify_ranges(R, b.keys_sorted, img.ranges, s); } // K8
         C3DGS_STAGE("identify_ranges", p.debug, s);
     }
     { StageTimer t_(ST_RENDER_FWD, s);
       // per-instance quadrant masks go to the (now idle) sort scratch: R bytes the backward reads instead of recomputing
-      launch_render_forward(W, H, img, b.point_list, g.splat, p.background, out_color, (uint8_t*)b.sort_temp, s); } // K9
+      launch_render_forward(W, H, img, b.point_list, g.splat, p.background, out_color, (uint8_t*)b.sort_temp, sort_err, s); } // K9
     C3DGS_STAGE("render_forward", p.debug, s);
     return C3DGS_OK;
 }
@@ -318,7 +328,7 @@ int c3dgs_debug_sort_pairs(int32_t key_bytes, int64_t n, int32_t end_bit, const 
         C3DGS_HIP_TRY(onesweep_depth_sort(temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)keys_out, values_in, values_out, (int)n,
                                           nullptr, nullptr, s));
     C3DGS_STAGE("debug_sort_pairs", 1, s);
-    if (onesweep_timed_out(temp, (size_t)n, key_bytes == 2 ? end_bit : 32, s)) return fail(C3DGS_E_HIP, "debug_sort_pairs: look-back timed out");
+    if (onesweep_timed_out(s)) return fail(C3DGS_E_HIP, "debug_sort_pairs: look-back timed out");
     return C3DGS_OK;
 }
 
@@ -357,6 +367,15 @@ int c3dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
     if (!means3D || !viewmatrix || !present) return fail(C3DGS_E_INVALID, "means3D, viewmatrix and present are required");
     { StageTimer t_(ST_MARK_VISIBLE, (hipStream_t)stream); launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream); }
     C3DGS_STAGE("mark_visible", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_camera_from_pose(const float* extrinsic_vector, float inv_tan_half_fovx, float inv_tan_half_fovy, float* viewmatrix,
+                           float* projmatrix, float* campos, void* stream)
+{
+    if (!extrinsic_vector || !viewmatrix || !projmatrix || !campos) return fail(C3DGS_E_INVALID, "camera_from_pose: NULL pointer");
+    launch_camera_from_pose(extrinsic_vector, inv_tan_half_fovx, inv_tan_half_fovy, viewmatrix, projmatrix, campos, (hipStream_t)stream);
+    C3DGS_STAGE("camera_from_pose", 0, (hipStream_t)stream);
     return C3DGS_OK;
 }
 

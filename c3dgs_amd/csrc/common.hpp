@@ -72,7 +72,7 @@ inline void geom_layout(int P, c3dgs_geom_layout* L)
     L->inst_offset = o;       o = align_up(o + p * 4);
     L->rects = o;             o = align_up(o + p * 8);
     L->clamped = o;           o = align_up(o + p);
-    L->block_base = o;        o = align_up(o + ((p + 255) / 256 + 1) * 4);
+    L->block_base = o;        o = align_up(o + ((p + 255) / 256 + 2) * 4);   // + num_rendered + sort error word
     L->depth_base = o;        o = align_up(o + ((p + 255) / 256 + 1) * 4);
     L->scan_temp = o;         L->scan_temp_bytes = scan_temp_bytes((int)p);
     o = align_up(o + L->scan_temp_bytes);
@@ -139,8 +139,9 @@ inline ImgPtrs img_ptrs(void* base, int W, int H)
 }
 
 // preprocess.hip
+void launch_camera_from_pose(const float* pose, float inv_tan_x, float inv_tan_y, float* view, float* proj, float* campos, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
-void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, hipStream_t s);
+void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, const uint32_t* sort_err, hipStream_t s);
 void launch_depth_order_scan(int P, const GeomPtrs& g, hipStream_t s);   // block totals of tiles_sorted -> depth_base[]
 void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, hipStream_t s);
 void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, hipStream_t s);
@@ -151,7 +152,8 @@ hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uin
                          uint32_t* vout, int R, int end_bit, hipStream_t s);
 // radix_sort.hip (hand-written onesweep; C3DGS_SORT_ROCPRIM=1 selects the rocPRIM path of binning.hip instead)
 bool onesweep_enabled();
-int onesweep_timed_out(const void* temp, size_t n, int total_bits, hipStream_t s);   // debug mode only (synchronises)
+int onesweep_timed_out(hipStream_t s);   // debug mode only (synchronises): reads + clears the sticky error word
+uint32_t* onesweep_error_word();          // device address of the sticky look-back time-out word (0 = fine)
 size_t onesweep_depth_temp_bytes(int P);
 size_t onesweep_tile_temp_bytes(int R, int end_bit);
 hipError_t onesweep_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
@@ -160,7 +162,7 @@ hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin
                               int R, int end_bit, hipStream_t s);
 // render.hip
 void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
-                           const float* bg, float* out_color, uint8_t* qmask, hipStream_t s);
+                           const float* bg, float* out_color, uint8_t* qmask, const uint32_t* sort_err, hipStream_t s);
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                             const uint32_t* block_base, const float* bg, const float* dL_dpix, float* partials,
                             uint8_t* touched, const uint8_t* qmask, uint32_t* tile_order, hipStream_t s);

@@ -35,6 +35,52 @@ void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t
     mark_visible_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, means3D, view, present);
 }
 
+// ---- camera set-up ON THE DEVICE, from the pose's live values: the host part of the reference's autograd wrappers
+// (DGR-NC __init__.py:32-40 quat_to_mat, :152-172 `extrinsic @ getProjectionMatrix(...)`, `extrinsic.inverse()[3, :3]`).
+// The reference evaluates quat_to_mat with fp32 tensor arithmetic on the pose's elements; the same fp32 operations in the
+// same order run here (this file is built with -ffp-contract=off), stream-ordered behind whatever last wrote the pose --
+// so an optimiser that updates the pose through raw pointers or `.data` can never be rendered with a stale matrix, and
+// no device->host read is needed. view is stored transposed like the reference's (m[0], m[4], m[8], m[12] = row 0).
+__global__ void camera_from_pose_kernel(const float* __restrict__ pose, float inv_tan_x, float inv_tan_y, float pa, float pb,
+                                        float* __restrict__ view, float* __restrict__ proj, float* __restrict__ campos)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float x = pose[0], y = pose[1], z = pose[2], w = pose[3], tx = pose[4], ty = pose[5], tz = pose[6];
+    const float d2 = y * y + z * z + x * x;
+    float M[4][4];                                             // world -> camera, row major
+    M[0][0] = 1.0f + 2.0f * (x * x - d2); M[0][1] = 2.0f * (x * y - w * z);        M[0][2] = 2.0f * (x * z + w * y);        M[0][3] = tx;
+    M[1][0] = 2.0f * (x * y + w * z);        M[1][1] = 1.0f + 2.0f * (y * y - d2); M[1][2] = 2.0f * (y * z - w * x);        M[1][3] = ty;
+    M[2][0] = 2.0f * (x * z - w * y);        M[2][1] = 2.0f * (y * z + w * x);        M[2][2] = 1.0f + 2.0f * (z * z - d2); M[2][3] = tz;
+    M[3][0] = 0.f; M[3][1] = 0.f; M[3][2] = 0.f; M[3][3] = 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) view[i * 4 + j] = M[j][i];
+        // row i of view @ P^T with P^T = [[ix,0,0,0],[0,iy,0,0],[0,0,a,1],[0,0,b,0]] (getProjectionMatrix, znear .01 zfar 100)
+        proj[i * 4 + 0] = M[0][i] * inv_tan_x;
+        proj[i * 4 + 1] = M[1][i] * inv_tan_y;
+        proj[i * 4 + 2] = M[2][i] * pa + M[3][i] * pb;
+        proj[i * 4 + 3] = M[2][i];
+    }
+    // inverse(view)[3, :3] = -R^-1 t (camera centre); adjugate in double, R is not assumed orthonormal (the pose's quaternion
+    // is not normalised by the reference either)
+    const double a = M[0][0], b = M[0][1], c = M[0][2], d = M[1][0], e = M[1][1], f = M[1][2], g = M[2][0], h = M[2][1], k = M[2][2];
+    const double A = e * k - f * h, B = -(d * k - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + c * C;
+    const double inv[3][3] = { { A / det, -(b * k - c * h) / det, (b * f - c * e) / det },
+                               { B / det, (a * k - c * g) / det, -(a * f - c * d) / det },
+                               { C / det, -(a * h - b * g) / det, (a * e - b * d) / det } };
+#pragma unroll
+    for (int r = 0; r < 3; r++) campos[r] = (float)-(inv[r][0] * (double)tx + inv[r][1] * (double)ty + inv[r][2] * (double)tz);
+}
+
+void launch_camera_from_pose(const float* pose, float inv_tan_x, float inv_tan_y, float* view, float* proj, float* campos, hipStream_t s)
+{
+    // torch.Tensor([...]) rounds getProjectionMatrix's double entries to fp32 (__init__.py:25-30)
+    const float pa = (float)(1.0 * 100.0 / (100.0 - 0.01)), pb = (float)(-(100.0 * 0.01) / (100.0 - 0.01));
+    camera_from_pose_kernel<<<1, 64, 0, s>>>(pose, inv_tan_x, inv_tan_y, pa, pb, view, proj, campos);
+}
+
 // ---- SH -> RGB, reference forward.cu:20-79. `c` holds the (DEG+1)^2 * 3 coefficients of this Gaussian.
 template <int DEG>
 __device__ __forceinline__ void sh_to_rgb(const float* c, float x, float y, float z, float out[3])
@@ -214,7 +260,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
 
 // exclusive scan of the workgroup totals, in place: base[b] = instances of all Gaussians before workgroup b;
 // base[nb] = num_rendered. One workgroup; nb = P/256 is a few thousand to a few ten-thousand.
-__global__ void __launch_bounds__(1024) scan_blocks_kernel(int nb, uint32_t* __restrict__ base)
+// `sort_err` (optional): the device's sticky sort time-out word, copied behind the total so that the forward's single
+// device->host read of num_rendered brings it along (radix_sort.hip).
+__global__ void __launch_bounds__(1024) scan_blocks_kernel(int nb, uint32_t* __restrict__ base, const uint32_t* __restrict__ sort_err)
 {
     __shared__ uint32_t s_w[2][16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -234,10 +282,13 @@ __global__ void __launch_bounds__(1024) scan_blocks_kernel(int nb, uint32_t* __r
         if (idx < nb) base[idx] = off + incl - v;
         carry += all;
     }
-    if (t == 0) base[nb] = carry;
+    if (t == 0) {
+        base[nb] = carry;
+        if (sort_err) base[nb + 1] = *sort_err;
+    }
 }
 
-void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, hipStream_t s)
+void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, const uint32_t* sort_err, hipStream_t s)
 {
     if (p.P <= 0) return;
     PreArgs a;
@@ -263,7 +314,7 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
         case 2: preprocess_kernel<2><<<grid, block, 0, s>>>(a); break;
         default: preprocess_kernel<3><<<grid, block, 0, s>>>(a); break;
     }
-    scan_blocks_kernel<<<1, 1024, 0, s>>>((int)grid.x, g.block_base);
+    scan_blocks_kernel<<<1, 1024, 0, s>>>((int)grid.x, g.block_base, sort_err);
 }
 
 // ---- K5: one (tile, Gaussian) pair per Gaussian x tile, reference rasterizer_impl.cu:70-111, walked in
@@ -343,7 +394,7 @@ void launch_depth_order_scan(int P, const GeomPtrs& g, hipStream_t s)
     if (P <= 0) return;
     const int nb = (P + 255) / 256;
     block_totals_kernel<<<nb, 256, 0, s>>>(P, g.sorted_offsets, g.depth_base);
-    scan_blocks_kernel<<<1, 1024, 0, s>>>(nb, g.depth_base);
+    scan_blocks_kernel<<<1, 1024, 0, s>>>(nb, g.depth_base, nullptr);
 }
 
 void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, hipStream_t s)

@@ -40,10 +40,18 @@ template <class K> struct OsShape {
 };
 constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_PRE = 2u << 30, OS_CNT_MASK = (1u << 30) - 1;
 constexpr int OS_MAX_PASSES = 4;
-// every look-back spin is bounded (a predecessor's word normally arrives within microseconds); on time-out the pass
-// finishes with wrong offsets and raises word OS_ERR_WORD of the ticket block, which debug mode reads back
-constexpr uint32_t OS_SPIN_LIMIT = 1u << 22;
-constexpr int OS_ERR_WORD = 32;
+// Every look-back spin is bounded (a predecessor's word normally arrives within microseconds; tickets guarantee it is
+// running). On time-out the pass finishes with wrong offsets and raises the device's STICKY error word g_os_error, which
+//   * render_forward reads: a forward whose sorts timed out returns a NaN image instead of a plausible wrong one;
+//   * every forward copies to the host together with num_rendered (the one natural device->host read): the call fails
+//     with C3DGS_E_HIP and clears the word (c_abi.hip);
+//   * debug mode reads back synchronously after each sort.
+// C3DGS_OS_SPIN_LIMIT is a build parameter only so that a test build can force the time-out (tests/test_sort_gpu.py).
+#ifndef C3DGS_OS_SPIN_LIMIT
+#define C3DGS_OS_SPIN_LIMIT (1u << 22)
+#endif
+constexpr uint32_t OS_SPIN_LIMIT = C3DGS_OS_SPIN_LIMIT;
+__device__ uint32_t g_os_error;           // zero-initialised at module load; bit 0 = tile-key sort, bit 1 = depth-key sort
 
 struct OsPlan { int passes; int bits[OS_MAX_PASSES]; };
 
@@ -118,6 +126,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
                uint32_t n, int shift, const uint32_t* __restrict__ hist, uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
                const uint2* __restrict__ gather_src, uint2* __restrict__ gather_dst)
 {
+    constexpr uint32_t ERR_BIT = sizeof(K) == 2 ? 1u : 2u;
     constexpr uint32_t MASK = (1u << BITS) - 1;
     constexpr int OS_BLOCK = OsShape<K>::BLOCK, OS_IPT = OsShape<K>::IPT, OS_WAVES = OS_BLOCK / 64;
     __shared__ uint32_t s_cnt[OS_WAVES][OS_RADIX];   // per-wave digit counters, later exclusive prefixes across the waves
@@ -195,7 +204,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
             for (int64_t b = (int64_t)bid - 1;; b--) {
                 uint32_t s, spins = 0;
                 do { s = os_load(status + (size_t)b * OS_RADIX + tid); } while ((s >> 30) == 0 && ++spins < OS_SPIN_LIMIT);
-                if ((s >> 30) == 0) { atomicOr(ticket + OS_ERR_WORD, 1u); break; }   // never hang the device: give up, flag it
+                if ((s >> 30) == 0) { atomicOr(&g_os_error, ERR_BIT); break; }   // never hang the device: give up, flag it
                 pre += s & OS_CNT_MASK;
                 if (s & OS_FLAG_PRE) break;
             }
@@ -294,7 +303,7 @@ static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, 
         K* ko = p == plan.passes - 1 ? kout : tk[p & 1];
         uint32_t* vo = p == plan.passes - 1 ? vout : tv[p & 1];
         const bool last = p == plan.passes - 1;
-        // ticket + p is this pass's counter; the error word sits at a fixed distance behind the FIRST ticket
+        // ticket + p is this pass's counter
         os_launch_pass<K>(plan.bits[p], (unsigned)blocks, s, ki, ko, vi, vo, (uint32_t)n, shift, hist + (size_t)p * OS_RADIX,
                           status + (size_t)p * blocks * OS_RADIX, ticket + p, last ? gather_src : nullptr, last ? gather_dst : nullptr);
         shift += plan.bits[p];
@@ -302,18 +311,30 @@ static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, 
     return hipGetLastError();
 }
 
-// debug helper: did any look-back of the last sort in `temp` time out? (synchronises the stream)
-int onesweep_timed_out(const void* temp, size_t n, int total_bits, hipStream_t s)
+// address of the current device's sticky error word (cached per device; one process per GPU is the normal case)
+uint32_t* onesweep_error_word()
 {
-    if (!onesweep_enabled() || n == 0 || n >= ((size_t)1 << 30)) return 0;
-    const OsPlan plan = os_plan(total_bits);
-    // the depth sort (32 bits) runs on u32 keys, the tile sort (<= 16 bits) on u16 keys: their tile sizes may differ
-    const size_t nblocks = total_bits > 16 ? os_blocks<uint32_t>(n) : os_blocks<uint16_t>(n);
-    const uint32_t* ticket = (const uint32_t*)temp + (size_t)plan.passes * OS_RADIX + (size_t)plan.passes * nblocks * OS_RADIX;
-    uint32_t w[OS_MAX_PASSES] = { 0, 0, 0, 0 };
-    if (hipMemcpyAsync(w, ticket + OS_ERR_WORD, sizeof(w), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
+    static uint32_t* cache[64] = { nullptr };
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!cache[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_os_error)) != hipSuccess) return nullptr;
+        cache[dev] = (uint32_t*)p;
+    }
+    return cache[dev];
+}
+
+// debug helper: did any look-back so far time out on this device? (synchronises the stream; clears the word)
+int onesweep_timed_out(hipStream_t s)
+{
+    if (!onesweep_enabled()) return 0;
+    uint32_t* e = onesweep_error_word();
+    uint32_t w = 1;
+    if (!e || hipMemcpyAsync(&w, e, sizeof(w), hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
     if (hipStreamSynchronize(s) != hipSuccess) return 1;
-    return (w[0] | w[1] | w[2] | w[3]) != 0;
+    if (w) (void)hipMemsetAsync(e, 0, sizeof(w), s);
+    return w != 0;
 }
 
 bool onesweep_enabled()

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256)
 render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const float4* __restrict__ splat, const float* __restrict__ bg, float* __restrict__ out_color,
                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_used,
-                      uint8_t* __restrict__ qmask)
+                      uint8_t* __restrict__ qmask, const uint32_t* __restrict__ sort_err)
 {
     const int tile = tile_of_block(blockIdx.x, T);
     if (tile >= T || (blockIdx.x >> 3) >= ((T + 7) >> 3)) return;
@@ -224,9 +224,11 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
         const size_t pix = (size_t)W * py + px, HW = (size_t)H * W;
         final_T[pix] = Tr;
         n_contrib[pix] = last_contributor;
-        out_color[pix] = fmaf(Tr, bg[0], C0);
-        out_color[HW + pix] = fmaf(Tr, bg[1], C1);
-        out_color[2 * HW + pix] = fmaf(Tr, bg[2], C2);
+        // a sort whose look-back timed out (radix_sort.hip) leaves a mis-ordered list: return NaN, not a plausible image
+        const float poison = *sort_err ? __uint_as_float(0x7fc00000u) : 0.f;
+        out_color[pix] = fmaf(Tr, bg[0], C0) + poison;
+        out_color[HW + pix] = fmaf(Tr, bg[1], C1) + poison;
+        out_color[2 * HW + pix] = fmaf(Tr, bg[2], C2) + poison;
     }
     // tile_used = max over the tile's pixels of n_contrib: the backward never looks past it
     atomicMax(&s_used, last_contributor);
@@ -235,12 +237,12 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
 }
 
 void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
-                           const float* bg, float* out_color, uint8_t* qmask, hipStream_t s)
+                           const float* bg, float* out_color, uint8_t* qmask, const uint32_t* sort_err, hipStream_t s)
 {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     const int grid = ((T + 7) / 8) * 8;
     render_forward_kernel<<<grid, 256, 0, s>>>(W, H, gx, T, img.ranges, point_list, splat, bg, out_color, img.final_T,
-                                               img.n_contrib, img.tile_used, qmask);
+                                               img.n_contrib, img.tile_used, qmask, sort_err);
 }
 
 // ---------------------------------------------------------------- backward

@@ -85,6 +85,15 @@ typedef struct c3dgs_raster_grads {
     float* dL_drotations;     /* [P,4]   | indexed: [GS,4]    (scatter-added)                 */
 } c3dgs_raster_grads;
 
+/* ---- camera set-up of the reference's autograd wrappers, on the device (DGR-NC .../__init__.py:32-40 quat_to_mat,
+ * :19-30 getProjectionMatrix, :152-172 `extrinsic @ getProjectionMatrix(intrinsic)` and `extrinsic.inverse()[3, :3]`).
+ * extrinsic_vector = device float[7] (qx, qy, qz, qw, tx, ty, tz), read in stream order -- the matrices always belong
+ * to the pose's CURRENT values, whatever wrote them. inv_tan_half_fov* = 1 / tan(FoV / 2) as fp32 (the two
+ * intrinsic-dependent entries of getProjectionMatrix). Outputs: viewmatrix[16], projmatrix[16] (both transposed like
+ * the reference's), campos[3]. */
+int c3dgs_camera_from_pose(const float* extrinsic_vector, float inv_tan_half_fovx, float inv_tan_half_fovy,
+                           float* viewmatrix, float* projmatrix, float* campos, void* stream);
+
 /* ---- _C.mark_visible (rasterize_points.cu:202-221 -> rasterizer_impl.cu:54-66,141-149) ---- */
 int c3dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                        uint8_t* present /*[P] bool*/, void* stream);

@@ -120,12 +120,15 @@ def projection_matrix(intrinsic):
 
 
 def quat_to_mat(ev):
-    """quat_to_mat, DGR-NC __init__.py:32-40 (returned TRANSPOSED)."""
-    x, y, z, w, tx, ty, tz = [float(v) for v in ev]
+    """quat_to_mat, DGR-NC __init__.py:32-40 (returned TRANSPOSED). The reference evaluates the entries with fp32 tensor
+    arithmetic on the elements of the pose, left to right; same fp32 operations here (pinned by tests/golden/camera.npz)."""
+    f = np.float32
+    x, y, z, w, tx, ty, tz = [f(v) for v in np.asarray(ev, dtype=np.float32)]
+    one, two = f(1.0), f(2.0)
     d2 = y * y + z * z + x * x
-    m = np.array([[1.0 + 2.0 * (x * x - d2), 2.0 * (x * y - w * z), 2.0 * (x * z + w * y), tx],
-                  [2.0 * (x * y + w * z), 1.0 + 2.0 * (y * y - d2), 2.0 * (y * z - w * x), ty],
-                  [2.0 * (x * z - w * y), 2.0 * (y * z + w * x), 1.0 + 2.0 * (z * z - d2), tz],
+    m = np.array([[one + two * (x * x - d2), two * (x * y - w * z), two * (x * z + w * y), tx],
+                  [two * (x * y + w * z), one + two * (y * y - d2), two * (y * z - w * x), ty],
+                  [two * (x * z - w * y), two * (y * z + w * x), one + two * (z * z - d2), tz],
                   [0, 0, 0, 1.0]], dtype=np.float32)
     return np.ascontiguousarray(m.T)
 

@@ -92,14 +92,39 @@ def compare(inp, cam, indexed, st, ref=None, dL=None, fw=None):
     rg = st.ranges.astype(np.int64)
     out["deepest_tile_list"] = int((rg[:, 1] - rg[:, 0]).max()) if rg.size else 0
     out["deepest_blend"] = int(st.n_contrib.max()) if st.n_contrib.size else 0
+    # Pixels where an ulp of exp() flips a threshold decision (alpha >= 1/255, T < 1e-4) between the two implementations:
+    # n_contrib differs, or the colour moves by one borderline contribution. Any two exp() implementations (CUDA's expf,
+    # glibc's, v_exp_f32) disagree on a few of the ~10^9 decisions of a 1080p view; everything else agrees to ~1e-7.
+    flipped = (u["n_contrib"] != st.n_contrib).reshape(st.H, st.W) | (np.abs(a - b) > 2e-5 + 1e-4 * np.abs(b)).any(0)
+    out["flipped_pixels"] = int(flipped.sum())
     if ref is not None:
         got = gpu_util.hip_backward(fw, dL)
-        errs = {}
+        # Gaussians that share a 16x16 tile with a flipped pixel: their gradients legitimately differ by that pixel's term
+        gx = (st.W + 15) // 16
+        ys, xs = np.nonzero(flipped)
+        tiles = np.unique((ys // 16) * gx + xs // 16)
+        affected = np.zeros(st.P, bool)
+        for t in tiles:
+            affected[st.point_list[st.ranges[t, 0]:st.ranges[t, 1]]] = True
+        out["gaussians_sharing_a_tile_with_a_flip"] = int(affected.sum())
+        rows_of = {"dL_dsh": st.inputs["sh_indices"], "dL_dscales": st.inputs["g_indices"], "dL_drotations": st.inputs["g_indices"]}
+        errs, errs_clean = {}, {}
         for k, v in got.items():
             r = ref[k]
             if r.size == 0 or v.shape != r.shape:
                 continue
-            errs[k] = float("inf") if not np.isfinite(v).all() else gpu_util.rel_inf(v, r)
+            if not np.isfinite(v).all():
+                errs[k] = errs_clean[k] = float("inf")
+                continue
+            errs[k] = gpu_util.rel_inf(v, r)
+            bad = affected
+            if rows_of.get(k) is not None and r.shape[0] != st.P:       # codebook-sized: rows any affected Gaussian points at
+                bad = np.zeros(r.shape[0], bool)
+                bad[rows_of[k][affected]] = True
+            d = np.abs(v.astype(np.float64) - r.astype(np.float64)).reshape(r.shape[0], -1).max(1)
+            errs_clean[k] = float(d[~bad].max() / max(np.abs(r).max(), 1e-30)) if (~bad).any() else 0.0
         out["grad_rel_inf"] = errs
         out["grad_rel_inf_max"] = max(errs.values()) if errs else 0.0
+        out["grad_rel_inf_excluding_flips"] = errs_clean
+        out["grad_rel_inf_excluding_flips_max"] = max(errs_clean.values()) if errs_clean else 0.0
     return out

@@ -14,6 +14,9 @@ What it pins; the fixtures hold data only (inputs + exp
   splats.npz     utils/splats.py: extract_rot_scale(to_full_cov(cov6)) and build_covariance of its result (pure torch,
                  importable): the eigendecomposition step of compress_covariance (compression/vq.py:186)
   lr.npz         utils/general_utils.py:get_expon_lr_func (the xyz learning-rate schedule of finetune.py's loop)
+  camera.npz     getProjectionMatrix / quat_to_mat / mat_to_quat (diff_gaussian_rasterization_no_camera/__init__.py:19-52,
+                 text executed with `.cuda()` dropped) and the camera set-up of the autograd wrappers built from them
+                 (:152-172: tan(FoV/2), H, W, `extrinsic @ getProjectionMatrix(...)`, `extrinsic.inverse()[3, :3]`)
   camgrad.npz    the closed-form grad_params block of _RasterizeGaussiansIndexedCamera.backward
                  (diff_gaussian_rasterization_no_camera/__init__.py:674-844), executed on CPU tensors
 """
@@ -144,6 +147,40 @@ def gen_camgrad():
     print("camgrad.npz")
 
 
+def gen_camera():
+    """Lines 19-52 of the rasterizer package's __init__.py are self-contained (math + torch); the package itself cannot be
+    imported (its `_C` extension is CUDA-only), so their text is executed here with the `.cuda()` calls dropped. fp32
+    element arithmetic on CPU tensors is the same IEEE arithmetic the reference runs on 0-dim CUDA tensors."""
+    import math
+    src = open(os.path.join(REF, "submodules/diff-gaussian-rasterization-no-camera/"
+                                 "diff_gaussian_rasterization_no_camera/__init__.py")).read().split("\n")
+    ns = dict(torch=torch, math=math)
+    exec("\n".join(src[18:52]).replace(".cuda()", ""), ns)
+    g = torch.Generator().manual_seed(31)
+    poses, intrs = [torch.tensor([0., 0, 0, 1, 0, 0, 0])], [torch.tensor([[1.35, 0, 1920.], [0, 0.85, 1080.], [0, 0, 1]])]
+    for k in range(7):
+        q = torch.randn(4, generator=g)
+        q = q / q.norm() if k < 5 else q * 0.7                 # the last two: NOT normalised (the reference never normalises)
+        poses.append(torch.cat([q, torch.randn(3, generator=g) * (0.3 + k)]).float())
+        fx, fy = float(torch.rand(1, generator=g)) * 1.5 + 0.3, float(torch.rand(1, generator=g)) * 1.2 + 0.3
+        intrs.append(torch.tensor([[fx, 0, float(100 + 237 * k)], [0, fy, float(50 + 131 * k)], [0, 0, 1]], dtype=torch.float32))
+    out = dict(extrinsic_vector=torch.stack(poses).numpy(), intrinsic=torch.stack(intrs).numpy())
+    views, Ps, projs, campos, scal, quats = [], [], [], [], [], []
+    for ev, intr in zip(poses, intrs):
+        extrinsic = ns["quat_to_mat"](ev)
+        Pm = ns["getProjectionMatrix"](intr)
+        views.append(extrinsic.numpy())
+        Ps.append(Pm.numpy())
+        projs.append((extrinsic @ Pm).numpy())                                     # __init__.py:171
+        campos.append(extrinsic.inverse()[3, :3].numpy())                          # :176
+        scal.append([float(math.tan(intr[0, 0] * 0.5)), float(math.tan(intr[1, 1] * 0.5)), int(intr[1, 2]), int(intr[0, 2])])  # :152-155
+        quats.append(torch.stack([torch.as_tensor(v) for v in ns["mat_to_quat"](extrinsic.transpose(0, 1))]).numpy())
+    out.update(view=np.stack(views), P=np.stack(Ps), proj=np.stack(projs), campos=np.stack(campos),
+               scalars=np.array(scal, dtype=np.float64), mat_to_quat=np.stack(quats))
+    np.savez_compressed(os.path.join(OUT, "camera.npz"), **out)
+    print("camera.npz")
+
+
 def gen_morton():
     """mortonEncode / splitBy3 (scene/gaussian_model.py:1417-1432) executed on the quantised positions of
     _sort_morton (:999-1003). The module itself is not importable (simple_knn, plyfile), the two functions are
@@ -221,12 +258,16 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["lr"]:
         gen_lr()
         sys.exit(0)
+    if sys.argv[1:] == ["camera"]:
+        gen_camera()
+        sys.exit(0)
     vq = shim_and_import_vq()
     gen_vq(vq, "vq_color.npz", N=3000, D=12, K=64, steps=12, chunk=1024, scale_normalize=False, seed=0)
     gen_vq(vq, "vq_cov.npz", N=2500, D=6, K=32, steps=10, chunk=512, scale_normalize=True, seed=1)
     gen_sh()
     gen_cov3d()
     gen_camgrad()
+    gen_camera()
     gen_loss()
     gen_morton()
     gen_splats()

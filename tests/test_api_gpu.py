@@ -180,3 +180,89 @@ def test_module_path_makes_no_device_allocations_in_steady_state(hip):
         assert torch.cuda.memory_reserved() == r0
     finally:
         gc.enable()
+
+
+def test_device_camera_setup_vs_reference_golden(hip):
+    """c3dgs_camera_from_pose (the matrices the rendering path really uses) against tests/golden/camera.npz, i.e. the
+    reference's quat_to_mat / getProjectionMatrix / camera set-up executed by make_golden.py: view bit-exact, `view @ P`
+    and `inverse(view)[3, :3]` to fp32 round-off; and bit-equal to the package's host restatement."""
+    import os
+    from c3dgs_amd import rasterizer as rz
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "camera.npz"), allow_pickle=False)
+    for k in range(d["extrinsic_vector"].shape[0]):
+        ev, intr = torch.from_numpy(d["extrinsic_vector"][k]), torch.from_numpy(d["intrinsic"][k])
+        view, proj, campos, tfx, tfy, H, W = rz.camera_matrices(intr.cuda(), ev.cuda(), "cuda")
+        assert view.is_cuda and view.shape == (4, 4) and proj.shape == (4, 4) and campos.shape == (3,)
+        np.testing.assert_array_equal(view.cpu().numpy().view(np.uint32), d["view"][k].view(np.uint32))
+        np.testing.assert_allclose(proj.cpu().numpy(), d["proj"][k], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(campos.cpu().numpy(), d["campos"][k], rtol=1e-5, atol=2e-6 * max(np.abs(d["campos"][k]).max(), 1.0))
+        assert (tfx, tfy, H, W) == (d["scalars"][k, 0], d["scalars"][k, 1], int(d["scalars"][k, 2]), int(d["scalars"][k, 3]))
+        hv, hp, hc = rz.camera_matrices(intr, ev, "cpu")[:3]
+        np.testing.assert_array_equal(view.cpu().numpy().view(np.uint32), hv.numpy().view(np.uint32))
+        np.testing.assert_array_equal(proj.cpu().numpy().view(np.uint32), hp.numpy().view(np.uint32))
+        np.testing.assert_array_equal(campos.cpu().numpy().view(np.uint32), hc.numpy().view(np.uint32))
+
+
+def _render_indexed(hip, rs, ix, evd):
+    rast = hip.GaussianRasterizerIndexed(rs, optimize_camera=True)
+    with torch.no_grad():
+        vis = rast.markVisible(ix["means3D"], extrinsic_vector=evd)
+        color, radii = rast(means3D=ix["means3D"], means2D=torch.zeros_like(ix["means3D"]), opacities=ix["opacities"],
+                            sh_indices=ix["sh_indices"], g_indices=ix["g_indices"], shs=ix["shs"], scales=ix["scales"],
+                            scale_factors=ix["scale_factors"], rotations=ix["rotations"], extrinsic_vector=evd)
+    return color.clone(), radii.clone(), vis.clone()
+
+
+def test_pose_written_behind_autograds_back_is_never_stale(hip):
+    """The camera matrices follow the pose tensor's CURRENT values whatever wrote them: a `.data` write (the reference's
+    own style, compression/vq.py:46), the package's fused Adam (raw-pointer writes, no version bump) and an in-place torch
+    op all change the very next render, and that render equals one with a fresh tensor holding the same values."""
+    from c3dgs_amd import optim
+    W, H, focal = 320, 200, 200.0
+    intr, ev = synth.camera(W, H, focal, extrinsic_vector=(0.05, -0.03, 0.02, 0.99, 0.1, -0.05, 0.2))
+    sc = synth.scene(6000, W, H, focal, seed=5, scale_median=0.03, behind_fraction=0.2)
+    ix = {k: v.cuda() for k, v in synth.index_scene(sc, shs_extra=64, gs_extra=64).items()}
+    rs = _settings(hip, intr, ev)
+    pose = ev.cuda().clone().requires_grad_()
+    c0, r0, v0 = _render_indexed(hip, rs, ix, pose)
+    # 1. `.data` write
+    pose.data[4:] += torch.tensor([0.4, -0.3, -3.5], device="cuda")
+    c1, r1, v1 = _render_indexed(hip, rs, ix, pose)
+    cf, rf, vf = _render_indexed(hip, rs, ix, pose.detach().clone())
+    assert not torch.equal(c0, c1) and not torch.equal(v0, v1)
+    assert torch.equal(c1, cf) and torch.equal(r1, rf) and torch.equal(v1, vf)
+    # 2. the fused Adam writes through raw pointers
+    opt = optim.Adam([{"params": [pose], "lr": 0.05}], lr=0.0, eps=1e-15)
+    pose.grad = torch.tensor([0.1, -0.2, 0.3, 0.0, 1.0, -1.0, 2.0], device="cuda")
+    before = pose.detach().clone()
+    opt.step()
+    assert not torch.equal(before, pose.detach())
+    c2, r2, v2 = _render_indexed(hip, rs, ix, pose)
+    cf, rf, vf = _render_indexed(hip, rs, ix, pose.detach().clone())
+    assert not torch.equal(c1, c2) and torch.equal(c2, cf) and torch.equal(r2, rf) and torch.equal(v2, vf)
+    # 3. an in-place torch op under no_grad
+    with torch.no_grad():
+        pose[6] += 0.7
+    c3, _, _ = _render_indexed(hip, rs, ix, pose)
+    assert not torch.equal(c2, c3) and torch.equal(c3, _render_indexed(hip, rs, ix, pose.detach().clone())[0])
+
+
+def test_intrinsic_written_through_data_is_noticed(hip):
+    """The host scalars taken from `intrinsic` (image size, tan FoV) are cached per tensor object; a `.data` write does not
+    bump the version counter, so the forward verifies the cache by value at its own synchronisation point and renders again."""
+    W, H, focal = 320, 200, 200.0
+    intr, ev = synth.camera(W, H, focal)
+    sc = synth.scene(3000, W, H, focal, seed=6, scale_median=0.03)
+    ix = {k: v.cuda() for k, v in synth.index_scene(sc, shs_extra=64, gs_extra=64).items()}
+    intr_d = intr.cuda()
+    rs = _settings(hip, intr_d, ev)
+    evd = ev.cuda()
+    c0, _, _ = _render_indexed(hip, rs, ix, evd)
+    c0b, _, _ = _render_indexed(hip, rs, ix, evd)                  # second call: served from the cache
+    assert c0.shape == (3, H, W) and torch.equal(c0, c0b)
+    intr2, _ = synth.camera(256, 160, 140.0)
+    intr_d.data.copy_(intr2.cuda())                                # same object, same version, new values
+    c1, _, _ = _render_indexed(hip, rs, ix, evd)
+    assert c1.shape == (3, 160, 256)
+    fresh = _render_indexed(hip, _settings(hip, intr2.cuda(), ev), ix, evd)[0]
+    assert torch.equal(c1, fresh)

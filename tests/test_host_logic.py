@@ -31,6 +31,23 @@ def test_camera_matrices_match_oracle_setup(orc):
     assert P.shape == (4, 4) and P[2, 3] == 1.0 and abs(P[3, 2].item() + 0.010001) < 1e-6   # transposed, znear .01 zfar 100
 
 
+def test_camera_helpers_vs_reference_functions():
+    """The package's own quat_to_mat / getProjectionMatrix / mat_to_quat / camera_matrices against tests/golden/camera.npz
+    (the reference's __init__.py:19-52, 152-176 executed by make_golden.py)."""
+    d = np.load(os.path.join(G, "camera.npz"), allow_pickle=False)
+    for k in range(d["extrinsic_vector"].shape[0]):
+        ev, intr = torch.from_numpy(d["extrinsic_vector"][k]), torch.from_numpy(d["intrinsic"][k])
+        np.testing.assert_array_equal(rz.quat_to_mat(ev).numpy().view(np.uint32), d["view"][k].view(np.uint32))
+        np.testing.assert_array_equal(rz.getProjectionMatrix(intr).numpy().view(np.uint32), d["P"][k].view(np.uint32))
+        q = torch.stack([torch.as_tensor(v) for v in rz.mat_to_quat(torch.from_numpy(d["view"][k]).T)])
+        np.testing.assert_allclose(q.numpy(), d["mat_to_quat"][k], rtol=1e-6, atol=1e-7)
+        view, proj, campos, tfx, tfy, H, W = rz.camera_matrices(intr, ev, "cpu")
+        np.testing.assert_array_equal(view.numpy().view(np.uint32), d["view"][k].view(np.uint32))
+        np.testing.assert_allclose(proj.numpy(), d["proj"][k], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(campos.numpy(), d["campos"][k], rtol=1e-5, atol=2e-6 * max(np.abs(d["campos"][k]).max(), 1.0))
+        assert (tfx, tfy, H, W) == (d["scalars"][k, 0], d["scalars"][k, 1], int(d["scalars"][k, 2]), int(d["scalars"][k, 3]))
+
+
 def test_mat_to_quat_roundtrip():
     ev = torch.tensor([0.05, -0.03, 0.02, 0.99, 0.1, -0.05, 0.2])
     ev[:4] /= ev[:4].norm()

@@ -75,3 +75,20 @@ def test_lr_schedule_matches_reference_golden():
         f = model.get_expon_lr_func(float(a), float(b), lr_delay_steps=int(d), lr_delay_mult=float(m), max_steps=int(n))
         got = np.array([f(int(st)) for st in z["steps"]])
         np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+
+
+def test_camera_setup_vs_reference_functions(orc):
+    """quat_to_mat / getProjectionMatrix and the wrappers' camera set-up (DGR-NC __init__.py:19-40, 152-176), executed
+    by make_golden.py: view and P bit-exact (fp32 element arithmetic / fp32-rounded doubles), `view @ P` and
+    `view.inverse()[3, :3]` to fp32 round-off of torch's CPU matmul / LU inverse."""
+    d = _load("camera.npz")
+    for k in range(d["extrinsic_vector"].shape[0]):
+        ev, intr = d["extrinsic_vector"][k], d["intrinsic"][k]
+        np.testing.assert_array_equal(orc.quat_to_mat(ev).view(np.uint32), d["view"][k].view(np.uint32))
+        np.testing.assert_array_equal(orc.projection_matrix(intr).view(np.uint32), d["P"][k].view(np.uint32))
+        cam = orc.camera(intr, ev)
+        np.testing.assert_allclose(cam["projmatrix"], d["proj"][k], rtol=2e-6, atol=1e-6)
+        scale = np.abs(d["campos"][k]).max()
+        np.testing.assert_allclose(cam["campos"], d["campos"][k], rtol=1e-5, atol=2e-6 * max(scale, 1.0))
+        assert cam["tan_fovx"] == d["scalars"][k, 0] and cam["tan_fovy"] == d["scalars"][k, 1]
+        assert (cam["H"], cam["W"]) == (int(d["scalars"][k, 2]), int(d["scalars"][k, 3]))
