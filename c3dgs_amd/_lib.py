@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libc3dgs_hip.so")
+# C3DGS_LIB_PATH: test hook only -- loads a variant build of the SAME library (c3dgs_amd/build.py VARIANTS)
+LIB_PATH = os.environ.get("C3DGS_LIB_PATH") or os.path.join(_HERE, "libc3dgs_hip.so")
 
 _f32p = C.POINTER(C.c_float)
 _i64p = C.POINTER(C.c_int64)

@@ -55,6 +55,34 @@ def _compile(name, extra, verbose):
     return obj
 
 
+# Test-only variants of the library: same sources, extra flags for some files; objects of untouched files are shared with
+# the product build. "spin1": every look-back of the radix sorts gives up after ONE poll, which forces the time-out path
+# that tests/test_sort_gpu.py::test_sort_timeout_is_not_silent exercises (loaded through C3DGS_LIB_PATH in a child process).
+VARIANTS = {"spin1": {"radix_sort.hip": ["-DC3DGS_OS_SPIN_LIMIT=1u"]}}
+
+
+def build_variant(name, verbose=False):
+    build(verbose=verbose)
+    odir = os.path.join(HERE, "build", "variant_" + name)
+    os.makedirs(odir, exist_ok=True)
+    lib = os.path.join(HERE, f"libc3dgs_hip_{name}.so")
+    objs, rebuilt = [], False
+    for src, extra in SOURCES.items():
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if src in VARIANTS[name]:
+            obj = os.path.join(odir, src.replace(".hip", ".o"))
+            if _stale(obj, [os.path.join(CSRC, src)] + HEADERS + [os.path.abspath(__file__)]):
+                cmd = [HIPCC] + COMMON + extra + VARIANTS[name][src] + ["-c", os.path.join(CSRC, src), "-o", obj]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                subprocess.check_call(cmd)
+                rebuilt = True
+        objs.append(obj)
+    if rebuilt or _stale(lib, objs):
+        subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     deps_common = HEADERS + [os.path.abspath(__file__)]
@@ -77,3 +105,6 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    if "--variants" in sys.argv:
+        for v in VARIANTS:
+            print(build_variant(v, verbose="--verbose" in sys.argv or "-v" in sys.argv))

@@ -75,3 +75,53 @@ def test_rocprim_fallback_gives_the_same_sorted_lists():
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+_TIMEOUT_CHILD = r"""
+import numpy as np, torch, sys
+from tests import cases, gpu_util, synth
+from oracle import oracle as orc
+from c3dgs_amd import _lib
+assert _lib.LIB_PATH.endswith("libc3dgs_hip_spin1.so"), _lib.LIB_PATH
+intr, ev = synth.camera(640, 360, 400.0)
+cam = orc.camera(intr.numpy(), ev.numpy())
+sc = synth.scene(400_000, 640, 360, 400.0, seed=3, scale_median=0.02)
+inp = dict(bg=torch.zeros(3), means3D=sc["means3D"], opacities=sc["opacities"], shs=sc["shs"], scales=sc["scales"],
+           rotations=sc["rotations"], degree=3, clamp_color=True)
+fw = gpu_util.hip_forward(inp, cam, False)           # 49 depth-sort tiles, hundreds of tile-sort tiles: look-backs give up
+torch.cuda.synchronize()
+assert torch.isnan(fw["color"]).all(), "a forward whose sort timed out must return a NaN image"
+try:
+    gpu_util.hip_forward(inp, cam, False)
+except RuntimeError as e:
+    assert "look-back timed out in an earlier rasterizer call" in str(e), str(e)
+    print("RAISED")
+else:
+    sys.exit("the call after a timed-out sort did not fail")
+# debug mode reports it in the same call
+a = list(fw["args"]); a[-2] = True
+from c3dgs_amd import rasterizer as rz
+try:
+    rz._C.rasterize_gaussians(*a)
+except RuntimeError as e:
+    assert "look-back timed out" in str(e), str(e)
+    print("DEBUG_RAISED")
+"""
+
+
+def test_sort_timeout_is_not_silent():
+    """A look-back that gives up (pre-empted / dead predecessor) must not yield a plausible wrong image outside debug mode:
+    with the `spin1` variant of the library (C3DGS_OS_SPIN_LIMIT=1: every look-back gives up after one poll) the forward
+    returns a NaN image, the next forward fails with C3DGS_E_HIP, and debug mode fails in the same call."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "c3dgs_amd", "libc3dgs_hip_spin1.so")
+    if not os.path.exists(lib):
+        from c3dgs_amd import build
+        build.build_variant("spin1")
+    r = subprocess.run([sys.executable, "-c", _TIMEOUT_CHILD], cwd=root, env=dict(os.environ, C3DGS_LIB_PATH=lib),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "RAISED" in r.stdout and "DEBUG_RAISED" in r.stdout, r.stdout
