@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1 under torch.distributed.run (WORLD_SIZE set): this process is one rank.
+        N > 1 started plainly: the parent starts N rank processes itself (one per GPU, RCCL rendezvous on 127.0.0.1) BEFORE it
+        touches the GPU, relays rank 0's JSON line and exits with the worst child code.
 
 Metric (BASELINE.json): raster views/sec, forward+backward, 1920x1080.  The N=1 workload is
 BASELINE.json configs[2]: 3M synthetic Gaussians (synth-v1), SH degree 3, the indexed-camera rasterizer the QAT loop
@@ -13,7 +16,13 @@ Extra objects on the same JSON line:
   roofline      dominant kernel: algorithmic bytes per launch (SURVEY.md 8(d) formula) / live HIP-event duration
   cpu_baseline  the oracle (CPU restatement, OpenMP) timed on this box's host cores on a bounded sample
   stages        per-stage mean ms from the same HIP events (all kernels of the view)
-  vq            sensitivity-weighted VQ Lloyd steps/s on config 4's colour shape, sharded over the N ranks (RCCL)
+  parity        HIP vs oracle on THIS workload at full size (integers equal, PSNR, gradient rel-inf; tests/fullsize.py),
+                reusing the oracle view the cpu_baseline leg computes (N = 1 only)
+  roofline_blend  the roofline object of BOTH blend kernels (render_forward, render_backward)
+  ranks_seen    all-reduce of ones over the job's ranks (must equal n_gpus)
+  vq            sensitivity-weighted VQ Lloyd steps/s on config 4's colour shape THROUGH c3dgs_amd.vq_features(group=...)
+                itself (batch draws, collectives and EMA update included), sharded over the N ranks (RCCL), its final
+                assignment, and (N = 1) vq.cpu_baseline: the reference's PyTorch-CPU loop restated (oracle/vq_torch.py)
   (N = 1 only)  qat_loop: the step + fused L1/SSIM loss; qat_model: the whole QAT view / iteration from raw parameters (fused
                 glue + fused Adam next to the reference's torch glue + torch Adam); postvq_index_layout: the headline step with
                 the codebook indices laid out as compression/vq.py's join_features produces them
@@ -75,6 +84,57 @@ def build_workload(P, W, H, focal, device):
     return intr, ev, t, dL, ix
 
 
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` started without a launcher: start N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+    torch.distributed.run would set them) from a parent that has NOT touched the GPU, relay rank 0's stdout, return the worst
+    exit code. Children are ordinary child processes (no exec of a GPU-initialised process anywhere)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import tempfile
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    while any(p.poll() is None for p in procs):
+        failed = [p for p in procs if p.poll() not in (None, 0)]
+        if failed:                                    # a dead rank leaves the others waiting in a collective: stop them
+            worst = max(abs(p.returncode) for p in failed)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.1)
+    worst = max([worst] + [abs(p.wait()) for p in procs])
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
+    return worst
+
+
+def selftest_launch(backend):
+    """Rendezvous + one all-reduce + the JSON line, nothing else: what the CPU test of the launcher runs (gloo)."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend)
+    ones = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(ones)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test", "n_gpus": world, "ranks_seen": int(ones.item()), "selftest": True}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,17 +145,33 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vq", action="store_true")
-    ap.add_argument("--vq-steps", type=int, default=10)
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-GPU extra lines (qat_loop, qat_model, postvq layout)")
+    ap.add_argument("--vq-steps", type=int, default=30)
+    ap.add_argument("--selftest-launch", default=None, metavar="BACKEND", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become the launcher (before anything initialises the GPU in this process)
+        if args.selftest_launch is None and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.selftest_launch is not None:
+        return selftest_launch(args.selftest_launch)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
 
     import c3dgs_amd
     from c3dgs_amd import _lib
@@ -188,13 +264,25 @@ def main():
     stage_ms = {k: v[0] / max(v[1], 1) for k, v in stages.items()}
     stage_ms[dom] = dom_live[dom][0] / max(dom_live[dom][1], 1)     # the timed region's own measurement
     raster_stages = [k for k in stage_ms if k in raster_names and k != "depth_sort"]
-    traffic = None
-    try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/pmc_traffic.sh)
+    # HBM bytes per launch: rocprofv3 --pmc passes of THIS command (tools/pmc_traffic.sh runs bench.py under the profiler and
+    # writes profiles/traffic_latest.json; counters cannot be read from inside the process that is being timed)
+    traffic_all, traffic_src = {}, None
+    try:
         if P == 3_000_000 and (W, H) == (1920, 1080):
             with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
-                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_all = json.load(f)
+            traffic_src = "profiles/traffic_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py --no-vq " \
+                          "--no-cpu-baseline --no-extras` (tools/pmc_traffic.sh; counters cannot be read inside the timed process)"
     except Exception:
-        traffic = None
+        traffic_all = {}
+    traffic = traffic_all.get(dom, {}).get("hbm_bytes_per_launch")
+
+    def roofline_of(k):
+        b = alg_bytes(k, P, V, R, T, N, 16, bit, indexed=True)
+        gbs = b / (stage_ms[k] * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": k, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": traffic_all.get(k, {}).get("hbm_bytes_per_launch"), "alg_bytes_per_launch": b,
+                "avg_launch_ms": stage_ms[k]}
     dom_bytes = alg_bytes(dom, P, V, R, T, N, 16, bit, indexed=True)
     dom_gbs = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
     view_bytes = sum(alg_bytes(k, P, V, R, T, N, 16, bit, True) for k in raster_stages)
@@ -204,6 +292,7 @@ def main():
         "value": world * args.steps / elapsed,
         "unit": "views/s",
         "n_gpus": world,
+        "ranks_seen": ranks_seen,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
@@ -219,7 +308,8 @@ def main():
                    "parallelism": f"replicas x{world}"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": dom_bytes,
-                     "avg_launch_ms": stage_ms[dom]},
+                     "avg_launch_ms": stage_ms[dom], "traffic_source": traffic_src},
+        "roofline_blend": {k: roofline_of(k) for k in ("render_forward", "render_backward") if k in stage_ms},
         "stages_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])},
         # informational: kernels of one step (untimed profiling pass) vs the timed step. A ratio far above 1 means the
         # GPU sat idle waiting for the host during the timed region (seen once on a heavily loaded box: profiles/README.md)
@@ -233,7 +323,7 @@ def main():
     # optimizer / FakeQuantize glue): extra, not the headline
     # (single-GPU extras: with N replicas they would only repeat the headline's weak scaling, behind more barriers)
     try:
-        if world > 1:
+        if world > 1 or args.no_extras:
             raise _SkipExtra()
         from c3dgs_amd import loss as lossm
         gt = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
@@ -264,7 +354,7 @@ def main():
     # Gaussians point into the 4096-row VQ codebook, the kept ones own one row each, in Gaussian order. synth-v1's indices
     # (the headline) are uniformly random over the whole codebook -- the worst case for the codebook gathers.
     try:
-        if world > 1:
+        if world > 1 or args.no_extras:
             raise _SkipExtra()
         out["postvq_index_layout"] = bench_postvq_layout(step, t, P, args.steps, dev, _lib)
     except _SkipExtra:
@@ -276,7 +366,7 @@ def main():
     # [visible] gathers) + raster + fused loss + backward -- through c3dgs_amd.model.GaussianModel.render (fused glue),
     # next to the reference's composition of the same glue from torch ops / torch.ao modules around the same rasterizer
     try:
-        if world > 1:
+        if world > 1 or args.no_extras:
             raise _SkipExtra()
         out["qat_model"] = bench_qat_model(c3dgs_amd, _lib, dev, ix_cpu, intr, evd, W, H, args.steps, barrier, world)
     except _SkipExtra:
@@ -287,14 +377,15 @@ def main():
     # ---- VQ (config 4 colour shape), sharded over the ranks with one all-reduce per Lloyd step
     if not args.no_vq:
         try:
-            out["vq"] = bench_vq(c3dgs_amd, _lib, dev, rank, world, args.vq_steps)
+            out["vq"] = bench_vq(c3dgs_amd, _lib, dev, rank, world, args.vq_steps, not args.no_cpu_baseline)
         except Exception as e:  # keep the headline line alive
             out["vq"] = {"error": repr(e)}
 
-    # ---- CPU baseline: the oracle on this box's host cores (rank 0, N=1 only)
+    # ---- CPU baseline: the oracle on this box's host cores (rank 0, N=1 only) -- and, from the same oracle view, the
+    # parity of the HIP path on this very workload
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(ix_cpu, intr, ev, W, H, focal)
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(ix_cpu, intr, ev, W, H, focal)
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
 
@@ -448,88 +539,134 @@ def bench_qat_model(c3dgs_amd, _lib, dev, ix_cpu, intr, evd, W, H, steps, barrie
     return res
 
 
-def bench_vq(c3dgs_amd, _lib, dev, rank, world, steps):
-    """Config 4 colour codebook: N=5.4M x 48 features, K=4096, batch 2^18 split over the ranks."""
+def bench_vq(c3dgs_amd, _lib, dev, rank, world, steps, cpu_baseline):
+    """Config 4 colour codebook: N=5.4M x 48 features, K=4096, batch 2^18 -- timed THROUGH the product entry point
+    c3dgs_amd.vq_features (compression/vq.py:49-87): batch draws, assignment, accumulation, the step's all-reduce over the
+    ranks and the EMA update are all inside the timed Lloyd loop; the sharded final assignment is timed separately."""
     from c3dgs_amd import vq as vqm
     g = torch.Generator(device=dev).manual_seed(7)
     N, D, K, B = 5_400_000, 48, 4096, 2 ** 18
     feats = torch.randn(N, D, device=dev, generator=g) * 0.1
     imp = torch.rand(N, device=dev, generator=g).pow(4)
-    model = vqm.VectorQuantize(D, K, decay=0.8).to(dev)
-    model.uniform_init(feats, torch.rand(K, D, device=dev, generator=g))
-    cpu_g = torch.Generator().manual_seed(11)
-    batches = [torch.randint(0, N, (B,), generator=cpu_g).to(dev) for _ in range(steps + 2)]
+    group = True if world > 1 else None
+    torch.manual_seed(11)                                     # the batch draws come from the CPU generator (vq.py:69)
 
-    scratch = {}
+    def run(n_steps, profile_stage=None):
+        st = {}
+        if profile_stage:
+            _lib.profile_enable(True, only=profile_stage)
+            _lib.profile_read()
+        vqm.vq_features(feats, imp, K, B, n_steps, silent=True, group=group, stats=st)
+        if profile_stage:
+            st["stage"] = _lib.profile_read().get(profile_stage, (0.0, 0))
+            _lib.profile_enable(False)
+        return st
 
-    def one(b):
-        lo, hi = (rank * B) // world, ((rank + 1) * B) // world
-        _, S, dsum = model.partial_sums(feats, imp, gather=b[lo:hi].contiguous(), scratch=scratch)
-        if world > 1:
-            S, dsum = vqm.all_reduce_sums(dist, None, S, dsum)
-        model.apply_sums(S)
-
-    for b in batches[:2]:
-        one(b)
+    run(3)                                                    # warm-up: RCCL communicators, allocator, pinned draw ring
+    first = run(1, "vq_accumulate")                           # the FIRST Lloyd step after uniform_init: every point lands on a
+    first_acc_ms = first["stage"][0] / max(first["stage"][1], 1)   # handful of codewords (worst-case contention of the sums)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    _lib.profile_enable(True)
-    _lib.profile_read()
-    t0 = time.perf_counter()
-    for b in batches[2:]:
-        one(b)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    st = _lib.profile_read()
-    _lib.profile_enable(False)
-    elt = torch.tensor([el], dtype=torch.float64, device=dev)
+    st = run(steps)                                           # timed: lloyd_seconds brackets exactly `steps` Lloyd steps
+    el = torch.tensor([st["lloyd_seconds"], st["final_assignment_seconds"]], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(elt, op=dist.ReduceOp.MAX)
-    el = float(elt.item())
-    wd_ms = st.get("weighted_distance", (0, 1))[0] / max(st.get("weighted_distance", (0, 1))[1], 1)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    lloyd_s, final_s = float(el[0]), float(el[1])
+    prof = run(steps, "weighted_distance")                    # untimed passes for the kernels' own durations
+    wd_ms = prof["stage"][0] / max(prof["stage"][1] - 1, 1) if prof["stage"][1] > 1 else 0.0   # (includes the final assignment launch)
+    acc = run(steps, "vq_accumulate")["stage"]
+    # the assignment launches of the Lloyd steps only: subtract the final assignment's share by timing it alone
+    only_final = run(0, "weighted_distance")["stage"]
+    wd_step_ms = (prof["stage"][0] - only_final[0]) / max(prof["stage"][1] - only_final[1], 1)
     flops = 2.0 * (B / world) * K * D
-    return {"metric": "vq_lloyd_steps_per_s", "value": steps / el, "ms_per_step": 1e3 * el / steps, "n_gpus": world,
-            "scaling": "strong", "config": {"workload": "config 4 colour: N=5.4M, D=48, K=4096, batch 2^18", "batch": B},
-            "assign_kernel_ms": wd_ms,
-            "roofline": {"bound": "mfma", "kernel": "weighted_distance", "achieved": flops / (wd_ms * 1e-3) / 1e12 if wd_ms else None,
-                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / (wd_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if wd_ms else None, "traffic": None}}
+    out = {"metric": "vq_lloyd_steps_per_s", "value": steps / lloyd_s, "unit": "steps/s", "ms_per_step": 1e3 * lloyd_s / steps,
+           "n_gpus": world, "scaling": "strong", "steps": steps,
+           "config": {"workload": "config 4 colour: N=5.4M, D=48, K=4096, batch 2^18 per step split over the ranks; "
+                                  "c3dgs_amd.vq_features(group=...) end to end", "batch": B},
+           "final_assignment_ms": 1e3 * final_s, "collectives_per_step": 1 if world > 1 else 0,
+           "assign_kernel_ms": wd_step_ms, "accumulate_kernel_ms": acc[0] / max(acc[1], 1),
+           "accumulate_first_step_ms": first_acc_ms,
+           "roofline": {"bound": "mfma", "kernel": "weighted_distance", "achieved": flops / (wd_step_ms * 1e-3) / 1e12 if wd_step_ms else None,
+                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / (wd_step_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if wd_step_ms else None, "traffic": None}}
+    del wd_ms
+    if cpu_baseline and rank == 0 and world == 1:
+        try:
+            out["cpu_baseline"] = vq_cpu_baseline(N, D, K, B)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
 
 
-def cpu_baseline(ix_cpu, intr, ev, W, H, focal):
+def vq_cpu_baseline(N, D, K, B):
+    """The reference's PyTorch-CPU VQ loop (compression/vq.py:28-35, 49-87) restated on CPU tensors (oracle/vq_torch.py; the
+    reference file does not travel and its two native extensions have no CPU build), all host cores, on a bounded sample:
+    the direct-difference search (reference-exact numerics) on 1/32 of a batch, the GEMM-form search on 1/4 of a batch;
+    per-step times scaled to the full 2^18-point batch. `value` is the FASTER (GEMM) form."""
+    from oracle import vq_torch
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    direct = vq_torch.time_lloyd_steps(N // 8, D, K, B, "direct", B // 32, 2, threads=cores)
+    gemm = vq_torch.time_lloyd_steps(N // 8, D, K, B, "gemm", B // 4, 3, threads=cores)
+    return {"value": 1.0 / gemm["seconds_per_step"], "unit": "steps/s", "cores": gemm["threads"], "kind": "port",
+            "sample": f"GEMM-form search: {gemm['steps']} Lloyd steps on {gemm['sample_points']}-point batches "
+                      f"({gemm['measured_seconds']:.2f} s), time scaled x{gemm['scale']:.0f} to the 2^18-point batch; "
+                      "oracle/vq_torch.py = compression/vq.py:28-35,49-87 on CPU tensors, torch.set_num_threads(all cores)",
+            "direct_difference_form": {"value": 1.0 / direct["seconds_per_step"], "unit": "steps/s",
+                                       "sample": f"{direct['steps']} steps on {direct['sample_points']}-point batches "
+                                                 f"({direct['measured_seconds']:.2f} s), scaled x{direct['scale']:.0f}"}}
+
+
+def cpu_baseline_and_parity(ix_cpu, intr, ev, W, H, focal):
     """The oracle (`kind: port`, oracle/c3dgs_oracle.c, OpenMP) on this box's host cores: one fwd+bwd view of the SAME
     workload. A 10 % Gaussian subsample is timed first; if that predicts more than ~45 s for the full view the scaled
-    subsample figure is reported instead (the sample field says which)."""
+    subsample figure is reported instead (the sample field says which). The oracle's view is then the checker of the HIP
+    path on the same inputs (tests/fullsize.py) -> `parity`."""
     import numpy as np
     from oracle import oracle as orc
-    from tests import synth
+    from tests import fullsize, synth
     cam = orc.camera(intr.numpy(), ev.numpy())
     P = ix_cpu["means3D"].shape[0]
     dL = synth.grad_image(W, H).numpy()
 
-    def run(n):
-        sel = slice(0, n)
-        t0 = time.perf_counter()
-        st = orc.rasterize_forward(bg=np.zeros(3, np.float32), means3D=ix_cpu["means3D"][sel].numpy(),
-                                   opacities=ix_cpu["opacities"][sel].numpy(), shs=ix_cpu["shs"].numpy(),
-                                   scales=ix_cpu["scales"].numpy(), rotations=ix_cpu["rotations"].numpy(),
-                                   scale_factors=ix_cpu["scale_factors"][sel].numpy(),
-                                   sh_indices=ix_cpu["sh_indices"][sel].numpy(), g_indices=ix_cpu["g_indices"][sel].numpy(),
-                                   degree=3, clamp_color=True, **cam)
-        orc.rasterize_backward(st, dL)
-        return time.perf_counter() - t0, st.num_rendered
+    def inputs(n):
+        return dict(bg=torch.zeros(3), means3D=ix_cpu["means3D"][:n], opacities=ix_cpu["opacities"][:n], shs=ix_cpu["shs"],
+                    colors_precomp=None, scales=ix_cpu["scales"], rotations=ix_cpu["rotations"], cov3D_precomp=None,
+                    scale_factors=ix_cpu["scale_factors"][:n], sh_indices=ix_cpu["sh_indices"][:n],
+                    g_indices=ix_cpu["g_indices"][:n], degree=3, scale_modifier=1.0, prefiltered=False, clamp_color=True)
 
     sub = max(1, P // 10)
-    dt_sub, r_sub = run(sub)
-    if dt_sub * (P / sub) <= 45.0:
-        dt, r = run(P)
-        return {"value": 1.0 / dt, "unit": "views/s", "cores": orc.num_threads(), "kind": "port",
-                "sample": f"1 full view fwd+bwd, {P} Gaussians at {W}x{H} ({dt:.2f} s, R={r}); oracle/c3dgs_oracle.c, OpenMP"}
-    scale = P / sub
-    return {"value": 1.0 / (dt_sub * scale), "unit": "views/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"1 view fwd+bwd of the first {sub} of {P} Gaussians at {W}x{H} ({dt_sub:.2f} s, R={r_sub}), "
-                      f"time scaled x{scale:.0f}; oracle/c3dgs_oracle.c, OpenMP"}
+    inp = inputs(sub)
+    st, ref, tf, tb = fullsize.oracle_view(inp, cam, dL)
+    n_used, dt = sub, tf + tb
+    if dt * (P / sub) <= 45.0:
+        inp = inputs(P)
+        st, ref, tf, tb = fullsize.oracle_view(inp, cam, dL)
+        n_used, dt = P, tf + tb
+        base = {"value": 1.0 / dt, "unit": "views/s", "cores": orc.num_threads(), "kind": "port",
+                "sample": f"1 full view fwd+bwd, {P} Gaussians at {W}x{H} ({dt:.2f} s, R={st.num_rendered}); "
+                          "oracle/c3dgs_oracle.c, OpenMP"}
+    else:
+        scale = P / sub
+        base = {"value": 1.0 / (dt * scale), "unit": "views/s", "cores": orc.num_threads(), "kind": "port",
+                "sample": f"1 view fwd+bwd of the first {sub} of {P} Gaussians at {W}x{H} ({dt:.2f} s, R={st.num_rendered}), "
+                          f"time scaled x{scale:.0f}; oracle/c3dgs_oracle.c, OpenMP"}
+    try:
+        parity = fullsize.compare(inp, cam, True, st, ref, dL)
+        parity["sample"] = f"HIP (C-ABI front-end) vs oracle, the first {n_used} of {P} Gaussians of the timed workload, fwd+bwd"
+        parity["bars"] = "integers equal; PSNR >= 80 dB; dPSNR <= 0.05 dB; grad rel-inf <= 1e-4 away from flipped pixels, <= 1e-3 overall"
+        parity["ok"] = bool(
+            parity["num_rendered_equal"] and parity["image_finite"] and parity["psnr_db"] >= 80.0 and parity["delta_psnr_db"] <= 0.05
+            and all(parity[k] == 0 for k in ("radii_mismatches", "tiles_touched_mismatches", "sorted_keys_mismatches",
+                                             "point_list_mismatches", "ranges_mismatches", "splat_float_bit_mismatches"))
+            and parity["grad_rel_inf_excluding_flips_max"] <= 1e-4 and parity["grad_rel_inf_max"] <= 1e-3)
+    except Exception as e:
+        parity = {"error": repr(e)}
+    return base, parity
 
 
 if __name__ == "__main__":

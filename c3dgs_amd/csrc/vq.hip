@@ -150,19 +150,27 @@ __device__ __forceinline__ void top2_update(float v, uint32_t code, uint32_t kee
     best = fminf(vp, best);
 }
 
-template <int MF_K>
+// SPLIT = false: the 4 waves of a workgroup own 64 points each and every wave scans the whole codebook tile.
+// SPLIT = true (small N, e.g. a rank's slice of a sharded Lloyd batch: 2^18 / 8 points are only 128 such workgroups on
+// 256 CUs): the 4 waves share ONE set of 64 points and split every 128-codeword tile into its four 32-codeword sub-tiles
+// (wave w takes sub-tile w), i.e. 4x as many workgroups for the same N; their (best, second, index) triples are merged
+// through LDS at the end. Same candidate values, same tie rule (lowest index) -> bit-identical results.
+template <int MF_K, bool SPLIT>
 __global__ void __launch_bounds__(256)
 wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather,
                const float* __restrict__ codebook, float* __restrict__ out_dist, int64_t* __restrict__ out_idx,
                int* __restrict__ flag_list, int flag_cap)
 {
     static_assert(MF_K % 2 == 0, "two dims per v_mfma_f32_32x32x2_f32 step");
+    static_assert(MF_CT / 32 == 4, "SPLIT hands one sub-tile of a tile to each of the 4 waves");
     __shared__ float s_cb[2][MF_K][MF_CT];   // k-major tile: lane i reads s_cb[k][i] (consecutive banks)
     __shared__ float s_norm[2][MF_CT];
+    __shared__ float s_mb[SPLIT ? 4 : 1][2][32], s_ms[SPLIT ? 4 : 1][2][32];
+    __shared__ int s_mi[SPLIT ? 4 : 1][2][32];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t n_base = ((int64_t)blockIdx.x * 4 + wave) * MF_PTS;
+    const int64_t n_base = SPLIT ? (int64_t)blockIdx.x * MF_PTS : ((int64_t)blockIdx.x * 4 + wave) * MF_PTS;
 
     // B operands: b[g][t] = -2 * x[n_base + 32g + i][2t + h]
     float b[2][MF_K / 2];
@@ -229,7 +237,7 @@ wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
         if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
         __syncthreads();
 #pragma unroll 1
-        for (int sub = 0; sub < MF_CT / 32; sub++) {
+        for (int sub = SPLIT ? wave : 0; sub < (SPLIT ? wave + 1 : MF_CT / 32); sub++) {
             if (tile * MF_CT + sub * 32 >= C) break;
             f32x16 acc0, acc1;
 #pragma unroll
@@ -263,9 +271,24 @@ wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
         const int my_idx = grp[g] * 32 + (code & 3) + 8 * (code >> 2) + 4 * h;
         const float ob = __shfl_xor(best[g], 32), os = __shfl_xor(second[g], 32);
         const int oi = __shfl_xor(my_idx, 32);
-        const float nb = fminf(best[g], ob);
-        const float ns = fminf(fminf(second[g], os), fmaxf(best[g], ob));
-        const int ni = (ob < best[g] || (ob == best[g] && oi < my_idx)) ? oi : my_idx;
+        float nb = fminf(best[g], ob);
+        float ns = fminf(fminf(second[g], os), fmaxf(best[g], ob));
+        int ni = (ob < best[g] || (ob == best[g] && oi < my_idx)) ? oi : my_idx;
+        if (SPLIT) {                                  // merge the four waves' triples (same points, disjoint codewords)
+            if (h == 0) { s_mb[wave][g][i] = nb; s_ms[wave][g][i] = ns; s_mi[wave][g][i] = ni; }
+            __syncthreads();
+            if (wave != 0) continue;
+            nb = s_mb[0][g][i]; ns = s_ms[0][g][i]; ni = s_mi[0][g][i];
+#pragma unroll
+            for (int w = 1; w < 4; w++) {
+                const float wb = s_mb[w][g][i], ws = s_ms[w][g][i];
+                const int wi = s_mi[w][g][i];
+                ns = fminf(fminf(ns, ws), fmaxf(nb, wb));
+                const bool take = wb < nb || (wb == nb && wi < ni);
+                nb = fminf(nb, wb);
+                ni = take ? wi : ni;
+            }
+        }
         const int64_t n = n_base + 32 * g + i;
         if (h == 0 && n < N) {
             const float db = nb + xnorm[g], ds = ns + xnorm[g];
@@ -425,13 +448,16 @@ static void launch_wd_mfma(int64_t N, int C, const float* coefs, const int64_t* 
                            int64_t* out_idx, int* flag_list, int flag_cap, hipStream_t s)
 {
     const unsigned g1 = (unsigned)((N + 4 * MF_PTS - 1) / (4 * MF_PTS)), g2 = (unsigned)((N + 63) / 64);
-    if (flag_list && flag_cap > 0 && N < ((int64_t)1 << 31)) {
-        (void)hipMemsetAsync(flag_list, 0, sizeof(int), s);
-        wd_mfma_kernel<K><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
+    // fewer than two 4-wave workgroups per CU (256 CUs): let the 4 waves share 64 points and split the codebook instead
+    static const int split_env = []() { const char* e = getenv("C3DGS_VQ_SPLIT"); return e ? atoi(e) : -1; }();   // A/B switch for tests
+    const bool split = split_env >= 0 ? split_env != 0 : g1 < 512;
+    const bool listed = flag_list && flag_cap > 0 && N < ((int64_t)1 << 31);
+    if (listed) (void)hipMemsetAsync(flag_list, 0, sizeof(int), s);
+    if (split) wd_mfma_kernel<K, true><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, listed ? flag_list : nullptr, listed ? flag_cap : 0);
+    else wd_mfma_kernel<K, false><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, listed ? flag_list : nullptr, listed ? flag_cap : 0);
+    if (listed) {
         const unsigned gl = (unsigned)std::min<int64_t>(1024, (flag_cap + WD_FB - 1) / WD_FB);
         wd_fixup_list_kernel<K><<<gl, 256, 0, s>>>(C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
-    } else {
-        wd_mfma_kernel<K><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, nullptr, 0);
     }
     wd_fixup_kernel<K><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);   // whatever is still flagged
 }
@@ -460,21 +486,82 @@ int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const 
 }
 
 // ---- VectorQuantize.update, part 1: weighted scatter-sums (compression/vq.py:31,33) into S[K, D+1].
-// Element e = n*(D+1)+c so that the D+1 atomics of one point are contiguous (one ~200-byte run per
-// point for D=48: the access shape the chip's memory-side float atomics run fastest on).
+// A wave takes 64 points at a time (lane = point: index, row, weight), finds the lanes that share a codeword with BITS
+// ballots (the match-any idiom of the radix sort's ranking), and then walks the GROUPS: the lanes turn into the D+1
+// channels of one codeword row, sum the group's members (coalesced row reads, weight broadcast by readlane) and issue ONE
+// contiguous (D+1)-float atomic run per group -- the access shape the chip's memory-side float atomics run fastest on.
+// Contention-aware by construction: right after uniform_init a handful of codewords win every point (a 2^18-point batch
+// used to pile 12.8 M atomics onto a few hundred addresses: 1.2 ms on the first Lloyd step against 0.08 ms later);
+// merged per wave that is 64x fewer atomics in the worst case and the same number in the contention-free one.
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 __global__ void __launch_bounds__(256)
-vq_accumulate_kernel(int64_t B, int D, const float* __restrict__ x, const float* __restrict__ w,
+vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x, const float* __restrict__ w,
                      const int64_t* __restrict__ gather, const int64_t* __restrict__ idx, float* __restrict__ S)
 {
     const int D1 = D + 1;
-    const int64_t total = B * D1;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t n = e / D1;
-        const int c = (int)(e - n * D1);
-        const int64_t row = gather ? gather[n] : n;
-        const float wn = w[row];
-        const float v = (c < D) ? x[row * D + c] * wn : wn;
-        atomicAdd(S + idx[n] * D1 + c, v);
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * 256) >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int64_t base = wave_id * 64; base < B; base += n_waves * 64) {
+        const int64_t n = base + lane;
+        const bool valid = n < B;
+        const int64_t row = valid ? (gather ? gather[n] : n) : 0;
+        const float wn = valid ? w[row] : 0.f;
+        const uint32_t id = valid ? (uint32_t)idx[n] : 0u;
+        unsigned long long peers = __ballot(valid);
+        for (int b = 0; b < idx_bits; b++) {
+            const bool bit = (id >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        unsigned long long leaders = __ballot(valid && (peers & lt) == 0ull);
+        if (D1 <= 64 && leaders == __ballot(valid)) {
+            // no two points of the chunk share a codeword (the steady state): four independent row loads in flight,
+            // then their four atomic runs
+            const int cnt = (int)__popcll(leaders);                  // valid lanes are 0 .. cnt-1
+            for (int j = 0; j < cnt; j += 4) {
+                float v[4];
+                float* dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int jj = min(j + u, cnt - 1);
+                    const int64_t rj = readlane_i64(row, jj);
+                    const float wj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(wn), jj));
+                    dst[u] = S + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)id, jj) * D1;
+                    v[u] = lane < D ? x[rj * D + lane] * wj : wj;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (j + u < cnt && lane < D1) atomicAdd(dst[u] + lane, v[u]);
+            }
+            continue;
+        }
+        while (leaders) {
+            const int l = __builtin_ctzll(leaders);
+            leaders &= leaders - 1;
+            const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)peers, l);
+            const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(peers >> 32), l);
+            unsigned long long members = ((unsigned long long)phi << 32) | plo;
+            float* dst = S + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)id, l) * D1;
+            for (int c0 = 0; c0 < D1; c0 += 64) {                    // D + 1 <= 64 for every codebook of the pipeline: one pass
+                const int c = c0 + lane;
+                float acc = 0.f;
+                for (unsigned long long m = members; m; m &= m - 1) {
+                    const int j = __builtin_ctzll(m);
+                    const int64_t rj = readlane_i64(row, j);
+                    const float wj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(wn), j));
+                    if (c < D) acc += x[rj * D + c] * wj;
+                    else if (c == D) acc += wj;
+                }
+                if (c < D1) atomicAdd(dst + c, acc);
+            }
+        }
     }
 }
 
@@ -528,15 +615,16 @@ vq_dist_sum_kernel(int64_t B, const float* __restrict__ dist, double* __restrict
 void launch_vq_accumulate(int64_t B, int K, int D, const float* x, const float* w, const int64_t* gather,
                           const int64_t* idx, const float* dist, float* S, double* dist_sum, hipStream_t s)
 {
-    (void)K;
     if (B <= 0) return;
     const int64_t total = B * (D + 1);
     if ((int64_t)K * (D + 1) <= VQ_LDS_FLOATS && total >= (int64_t)1 << 16) {
         const unsigned grid = (unsigned)std::min<int64_t>((total + 4095) / 4096, 512);
         vq_accumulate_lds_kernel<<<grid, 256, 0, s>>>(B, K, D, x, w, gather, idx, S);
     } else {
-        const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 16);
-        vq_accumulate_kernel<<<grid, 256, 0, s>>>(B, D, x, w, gather, idx, S);
+        int idx_bits = 1;
+        while (idx_bits < 32 && ((int64_t)1 << idx_bits) < (int64_t)K) idx_bits++;
+        const unsigned grid = (unsigned)std::min<int64_t>((B + 255) / 256, 256 * 16);        // one wave per 64 points
+        vq_accumulate_kernel<<<grid, 256, 0, s>>>(B, D, idx_bits, x, w, gather, idx, S);
     }
     if (dist && dist_sum) {
         const unsigned g2 = (unsigned)std::min<int64_t>((B + 255) / 256, 1024);

@@ -7,8 +7,10 @@
 Same names, argument meaning and error behaviour.  Additions (new functionality, BASELINE.json north_star):
   * `vq_features(..., group=...)`: every rank of a torch.distributed group draws the SAME batch, assigns its
     contiguous slice, and the per-cluster partial sums S[K, D+1] (sum w*x | sum w) plus the distance sum are
-    all-reduced (RCCL over xGMI when the backend is "nccl") once per Lloyd step; every rank then applies
-    the identical EMA update, so codebooks stay bit-identical across ranks.
+    all-reduced in place (RCCL over xGMI when the backend is "nccl") once per Lloyd step -- the only collective of a
+    step: the batch draws follow rank 0's CPU generator state, broadcast once (5 KB), and the per-step distance sums
+    are reduced once after the loop; every rank applies the identical EMA update, so codebooks stay bit-identical
+    across ranks.
   * `batches=` / `init_rand=`: the two RNG draws can be passed in as data (parity tests, sharded runs).
 There is no CPU path: tensors must live on the GPU and libc3dgs_hip.so must be present.
 """
@@ -88,9 +90,10 @@ class HipOps:
         return S, dsum
 
     @staticmethod
-    def sums(x, importance, gather, codebook, scratch=None):
+    def sums(x, importance, gather, codebook, scratch=None, dsum_out=None):
         """assign + accumulate as one library call (no intermediate tensors, no zero-fill launches). `scratch`: a dict
         that keeps the per-batch buffers (distances, indices, S) alive across steps of one loop; None allocates fresh.
+        `dsum_out`: an f64[1] device view the distance sum is written to (e.g. one slot of a per-step array).
         -> (min_dists f32[B], S f32[K, D+1], dist_sum f64[1])."""
         L = _lib.lib()
         K, D = int(codebook.shape[0]), int(x.size(1))
@@ -106,7 +109,7 @@ class HipOps:
                 scratch.clear()
                 scratch[key] = bufs
         dist, idx, S, flags = bufs
-        dsum = torch.empty(1, dtype=torch.float64, device=dev)
+        dsum = torch.empty(1, dtype=torch.float64, device=dev) if dsum_out is None else dsum_out
         xw = x.detach().contiguous().float()
         w = importance.detach().contiguous().float()
         cb = codebook.detach().contiguous().float()
@@ -147,14 +150,18 @@ class VectorQuantize(nn.Module):
         r = torch.rand_like(self.codebook) if rand is None else rand.to(self.codebook)
         self.codebook.data = r * (amax - amin) + amin
 
-    def partial_sums(self, x: torch.Tensor, importance: torch.Tensor, gather: Optional[torch.Tensor] = None, scratch=None):
+    def partial_sums(self, x: torch.Tensor, importance: torch.Tensor, gather: Optional[torch.Tensor] = None, scratch=None,
+                     dsum_out=None):
         """Assignment + weighted scatter-sums of one (slice of a) batch.
         Returns (min_dists f32[B], S f32[K, D+1] = [sum w*x | sum w], dist_sum f64[1]). With `scratch` (a dict owned by the
-        calling loop) min_dists and S are reused from step to step."""
+        calling loop) min_dists and S are reused from step to step; `dsum_out` receives the distance sum in place."""
         if hasattr(self.ops, "sums") and x.is_cuda:
-            return self.ops.sums(x, importance, gather, self.codebook.data, scratch)
+            return self.ops.sums(x, importance, gather, self.codebook.data, scratch, dsum_out)
         min_dists, idx = self.ops.assign(x, self.codebook.data, gather)
         S, dsum = self.ops.accumulate(x, importance, gather, idx, min_dists, int(self.codebook.shape[0]))
+        if dsum_out is not None:
+            dsum_out.copy_(dsum)
+            dsum = dsum_out
         return min_dists, S, dsum
 
     def apply_sums(self, S: torch.Tensor, scale_normalize: bool = False):
@@ -241,18 +248,9 @@ class _BatchDraws:
         self.key = None
 
 
-def all_reduce_sums(dist, pg, S: torch.Tensor, dsum: torch.Tensor):
-    """The exchange of a sharded Lloyd step as ONE collective: S f32[K, D+1] and, riding along as two more f32 words
-    (hi + lo), the f64 sum of distances. Returns the reduced (S, dsum f64[1]). (Two all-reduces of 0.8 MB and 8 bytes are
-    both latency-bound; over xGMI a ring collective costs tens of microseconds whatever its size.)"""
-    n = S.numel()
-    buf = torch.empty(n + 2, dtype=torch.float32, device=S.device)
-    buf[:n] = S.reshape(-1)
-    hi = dsum.to(torch.float32)
-    buf[n:n + 1] = hi
-    buf[n + 1:] = (dsum - hi.to(torch.float64)).to(torch.float32)
-    dist.all_reduce(buf, group=pg)
-    return buf[:n].view(S.shape), buf[n:].to(torch.float64).sum().reshape(1)
+def _sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize(dev)
 
 
 def _dist_info(group):
@@ -266,12 +264,15 @@ def _dist_info(group):
 def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size: int, vq_chunk: int = 2 ** 16,
                 steps: int = 1000, decay: float = 0.8, scale_normalize: bool = False, silent: bool = False,
                 group=None, batches=None, init_rand: Optional[torch.Tensor] = None, return_errors: bool = False,
-                shard_final: bool = True, ops=None, device_rng: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                shard_final: bool = True, ops=None, device_rng: bool = False, stats: Optional[dict] = None
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
     """compression/vq.py:49-87.  group=None: single GPU.  group=True (default process group) or a
     ProcessGroup: sharded Lloyd steps with one all-reduce of S[K, D+1] per step.
     The per-step `.item()` host sync of the reference (vq.py:71) is deferred to the end.
     Batch indices: by default the reference's draws exactly -- `torch.randint` on the CPU default generator (vq.py:69);
-    device_rng=True draws on the GPU instead (removes the host-RNG floor of ~2 ms/step, different numbers)."""
+    device_rng=True draws on the GPU instead (removes the host-RNG floor of ~2 ms/step, different numbers).
+    stats: optional dict that receives `lloyd_seconds`, `lloyd_steps`, `final_assignment_seconds` (wall clock, with a
+    device synchronisation at the two phase boundaries -- only when given)."""
     dist, rank, world = _dist_info(group)
     pg = None if group is True else group
     dev = features.device
@@ -285,29 +286,49 @@ def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size:
 
     feats = features.detach().contiguous().float()
     imp = importance_n.detach().contiguous().float()
-    err_sums = []
+    n_steps = steps if batches is None else len(batches)
+    err_local = torch.zeros(max(n_steps, 1), dtype=torch.float64, device=dev)       # per-step sums of min distances
+    batch_sizes = []
     scratch = {}
     it = range(steps) if batches is None else range(len(batches))
+    src_rank = (dist.get_global_rank(pg, 0) if pg is not None else 0) if world > 1 else 0
+    if world > 1 and batches is None and not device_rng:
+        # Every rank must draw the SAME batches. Not a broadcast of the indices per step (2 MB for a 2^18 batch, 8 MB for
+        # 2^20: more than the all-reduce it would accompany) but ONE broadcast of rank 0's CPU generator state (5 KB): all
+        # ranks then continue the same MT19937 stream themselves (csrc/draws.hip), and all are left at the same state.
+        st = torch.get_rng_state().to(dev)
+        dist.broadcast(st, src=src_rank, group=pg)
+        torch.set_rng_state(st.cpu())
     draws = None if batches is not None else _BatchDraws(N, vq_chunk, steps, dev, device_rng)
+    if stats is not None:
+        _sync(dev)
+        t_loop = time.perf_counter()
     try:
         for s in it:
             if batches is not None:
                 batch = batches[s].to(device=dev, dtype=torch.int64)
             else:
                 batch = draws.next_batch()
-                if world > 1:                                                       # every rank uses rank 0's draw
-                    dist.broadcast(batch, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
+                if world > 1 and device_rng:                                        # GPU generators differ per rank
+                    dist.broadcast(batch, src=src_rank, group=pg)
             B = int(batch.numel())
             lo, hi = (rank * B) // world, ((rank + 1) * B) // world
             with torch.no_grad():
-                _, S, dsum = vq_model.partial_sums(feats, imp, gather=batch[lo:hi].contiguous(), scratch=scratch)
+                # the slice's distance sum lands in this step's slot of err_local (reduced ONCE after the loop: the
+                # errors are reporting only); the exchange of the step is ONE in-place all-reduce of S[K, D+1]
+                _, S, _ = vq_model.partial_sums(feats, imp, gather=batch[lo:hi].contiguous(), scratch=scratch,
+                                                dsum_out=err_local[s:s + 1])
                 if world > 1:
-                    S, dsum = all_reduce_sums(dist, pg, S, dsum)
+                    dist.all_reduce(S, group=pg)
                 vq_model.apply_sums(S, scale_normalize=scale_normalize)
-            err_sums.append((dsum, B))
+            batch_sizes.append(B)
     finally:
         if draws is not None:
             draws.finish()
+    if stats is not None:
+        _sync(dev)
+        stats["lloyd_seconds"] = time.perf_counter() - t_loop
+        stats["lloyd_steps"] = len(batch_sizes)
     gc.collect()
 
     start = time.time()
@@ -323,10 +344,14 @@ def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size:
     if vq_indices.is_cuda:
         torch.cuda.synchronize(device=vq_indices.device)
     end = time.time()
+    if stats is not None:
+        stats["final_assignment_seconds"] = end - start
     if not silent:
         print(f"calculating indices took {end - start} seconds ")
     if return_errors:
-        errors = [float(d.item()) / max(b, 1) for d, b in err_sums]
+        if world > 1:
+            dist.all_reduce(err_local, group=pg)
+        errors = [float(d) / max(b, 1) for d, b in zip(err_local.tolist(), batch_sizes)]
         return vq_model.codebook.data.detach(), vq_indices.detach(), errors
     return vq_model.codebook.data.detach(), vq_indices.detach()
 

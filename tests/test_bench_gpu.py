@@ -25,6 +25,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     rf = d["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf) and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert d["device_allocs_in_timed_region"] == 0
+    assert d["device_allocs_in_timed_region"] == 0 and d["ranks_seen"] == 1
+    assert set(d["roofline_blend"]) == {"render_forward", "render_backward"}
+    assert all(0 < v["frac"] < 1 for v in d["roofline_blend"].values())
+    vq = d["vq"]
+    assert vq["value"] > 0 and vq["steps"] == 2 and vq["final_assignment_ms"] > 0 and vq["accumulate_first_step_ms"] > 0
     assert "error" not in json.dumps(d.get("qat_loop", {})) and "error" not in json.dumps(d.get("qat_model", {}))
     assert "error" not in json.dumps(d.get("vq", {})) and "error" not in json.dumps(d.get("postvq_index_layout", {}))

@@ -42,10 +42,28 @@ def _worker(rank, world, port, scale_normalize, out_dir):
     cb, idx, errs = vq.vq_features(f, imp, K, chunk, steps, scale_normalize=scale_normalize, silent=True, group=True,
                                    batches=batches, init_rand=init, return_errors=True, ops=OracleOps)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cb=cb.numpy(), idx=idx.numpy(), errs=np.array(errs))
-    # RNG-driven variant: rank 0's draws are broadcast, so ranks must still agree bit for bit
+    # RNG-driven variant: every rank continues rank 0's generator stream (its state is broadcast ONCE), so ranks must still
+    # agree bit for bit although they were seeded differently; and the collectives are counted: per Lloyd step exactly one
+    # all-reduce (of S) and no broadcast
     torch.manual_seed(100 + rank)
-    cb2, idx2 = vq.vq_features(f, imp, K, chunk, 3, scale_normalize=scale_normalize, silent=True, group=True, ops=OracleOps)
-    np.savez(os.path.join(out_dir, f"rng_rank{rank}.npz"), cb=cb2.numpy(), idx=idx2.numpy())
+    counts = {"all_reduce": 0, "broadcast": 0, "all_gather": 0}
+    orig = {k: getattr(dist, k) for k in counts}
+
+    def counting(name):
+        def f_(*a, **k):
+            counts[name] += 1
+            return orig[name](*a, **k)
+        return f_
+    for k in counts:
+        setattr(dist, k, counting(k))
+    try:
+        cb2, idx2 = vq.vq_features(f, imp, K, chunk, 3, scale_normalize=scale_normalize, silent=True, group=True, ops=OracleOps)
+    finally:
+        for k in counts:
+            setattr(dist, k, orig[k])
+    after = torch.randint(0, 1 << 30, (4,))                    # all ranks were left at the same generator state
+    np.savez(os.path.join(out_dir, f"rng_rank{rank}.npz"), cb=cb2.numpy(), idx=idx2.numpy(), after=after.numpy(),
+             counts=np.array([counts["all_reduce"], counts["broadcast"], counts["all_gather"]]))
     dist.destroy_process_group()
 
 
@@ -59,6 +77,10 @@ def test_sharded_vq_matches_single_rank(tmp_path, scale_normalize):
     q0, q1 = np.load(tmp_path / "rng_rank0.npz"), np.load(tmp_path / "rng_rank1.npz")
     np.testing.assert_array_equal(q0["cb"].view(np.uint32), q1["cb"].view(np.uint32))
     np.testing.assert_array_equal(q0["idx"], q1["idx"])
+    np.testing.assert_array_equal(q0["after"], q1["after"])
+    # 3 Lloyd steps: 3 all-reduces (one per step), 2 broadcasts in total (uniform_init's draw + the 5 KB generator state), one
+    # all_gather for the sharded final assignment
+    assert q0["counts"].tolist() == [3, 2, 1] and q1["counts"].tolist() == [3, 2, 1]
     # single rank, same draws
     from c3dgs_amd import vq
     from tests.oracle_ops import OracleOps

@@ -289,23 +289,3 @@ def test_pipeline_parameter_defaults_and_lr_schedule():
     g = model.get_expon_lr_func(1e-2, 1e-4, lr_delay_steps=100, lr_delay_mult=0.1, max_steps=1000)
     assert g(0) == pytest.approx(1e-2 * 0.1)
     assert g(50) == pytest.approx((0.1 + 0.9 * math.sin(0.25 * math.pi)) * math.exp(math.log(1e-2) * 0.95 + math.log(1e-4) * 0.05))
-
-
-def test_all_reduce_sums_packs_the_distance_sum_into_the_same_collective():
-    """c3dgs_amd.vq.all_reduce_sums: S and the f64 distance sum travel in one buffer (hi + lo f32 words)."""
-    from c3dgs_amd import vq
-
-    class ThreeIdenticalRanks:
-        calls = 0
-
-        def all_reduce(self, t, group=None):
-            ThreeIdenticalRanks.calls += 1
-            t.mul_(3)
-
-    g = torch.Generator().manual_seed(0)
-    S = torch.rand(64, 13, generator=g)
-    dsum = torch.tensor([123456.789012345678], dtype=torch.float64)
-    S2, d2 = vq.all_reduce_sums(ThreeIdenticalRanks(), None, S.clone(), dsum.clone())
-    assert ThreeIdenticalRanks.calls == 1
-    assert S2.shape == S.shape and S2.is_contiguous() and torch.equal(S2, S * 3)
-    assert d2.dtype == torch.float64 and d2.shape == (1,) and abs(float(d2) / (3 * float(dsum)) - 1) < 1e-6

@@ -92,3 +92,22 @@ def test_camera_setup_vs_reference_functions(orc):
         np.testing.assert_allclose(cam["campos"], d["campos"][k], rtol=1e-5, atol=2e-6 * max(scale, 1.0))
         assert cam["tan_fovx"] == d["scalars"][k, 0] and cam["tan_fovy"] == d["scalars"][k, 1]
         assert (cam["H"], cam["W"]) == (int(d["scalars"][k, 2]), int(d["scalars"][k, 3]))
+
+
+@pytest.mark.parametrize("name", ["vq_color.npz", "vq_cov.npz"])
+@pytest.mark.parametrize("form", ["direct", "gemm"])
+def test_torch_cpu_vq_restatement_vs_reference(name, form):
+    """oracle/vq_torch.py (the PyTorch-CPU VQ loop bench.py times as `vq.cpu_baseline`) reproduces the outputs of the
+    reference's own vq_features (compression/vq.py:49-87, run by make_golden.py) from the captured RNG draws: the direct
+    form to fp32 summation order, the GEMM form to its rounding (same argmin on all but near-ties)."""
+    import torch
+    from oracle import vq_torch
+    d = _load(name)
+    cb, idx, errs = vq_torch.vq_features(torch.from_numpy(d["features"]), torch.from_numpy(d["importance"]), int(d["K"]),
+                                         scale_normalize=bool(d["scale_normalize"]), form=form,
+                                         init_rand=torch.from_numpy(d["init_rand"]),
+                                         batches=[torch.from_numpy(b) for b in d["batches"]])
+    tol = 1e-6 if form == "direct" else 2e-4
+    np.testing.assert_allclose(cb.numpy(), d["codebook"], rtol=tol, atol=tol * 1e-2 + 1e-8)
+    assert (idx.numpy() == d["indices"]).mean() >= (1.0 if form == "direct" else 0.995)
+    assert len(errs) == len(d["batches"])
