@@ -521,24 +521,17 @@ vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x
             peers &= bit ? bal : ~bal;
         }
         unsigned long long leaders = __ballot(valid && (peers & lt) == 0ull);
-        if (D1 <= 64 && leaders == __ballot(valid)) {
-            // no two points of the chunk share a codeword (the steady state): four independent row loads in flight,
-            // then their four atomic runs
-            const int cnt = (int)__popcll(leaders);                  // valid lanes are 0 .. cnt-1
-            for (int j = 0; j < cnt; j += 4) {
-                float v[4];
-                float* dst[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int jj = min(j + u, cnt - 1);
-                    const int64_t rj = readlane_i64(row, jj);
-                    const float wj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(wn), jj));
-                    dst[u] = S + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)id, jj) * D1;
-                    v[u] = lane < D ? x[rj * D + lane] * wj : wj;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (j + u < cnt && lane < D1) atomicAdd(dst[u] + lane, v[u]);
+        if (leaders == __ballot(valid)) {
+            // no two points of the chunk share a codeword (the steady state): nothing to merge, so the chunk's cnt * (D+1)
+            // elements are added densely, 64 consecutive elements per instruction (every lane busy; a point's D+1 atomics
+            // stay contiguous)
+            const int total = (int)__popcll(leaders) * D1;
+            for (int e = lane; e < total; e += 64) {
+                const int j = e / D1, c = e - j * D1;
+                const int64_t nj = base + j;
+                const int64_t rj = gather ? gather[nj] : nj;
+                const float wj = w[rj];
+                atomicAdd(S + (size_t)idx[nj] * D1 + c, c < D ? x[rj * D + c] * wj : wj);
             }
             continue;
         }
@@ -552,12 +545,20 @@ vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x
             for (int c0 = 0; c0 < D1; c0 += 64) {                    // D + 1 <= 64 for every codebook of the pipeline: one pass
                 const int c = c0 + lane;
                 float acc = 0.f;
-                for (unsigned long long m = members; m; m &= m - 1) {
-                    const int j = __builtin_ctzll(m);
-                    const int64_t rj = readlane_i64(row, j);
-                    const float wj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(wn), j));
-                    if (c < D) acc += x[rj * D + c] * wj;
-                    else if (c == D) acc += wj;
+                unsigned long long m = members;
+                while (m) {                                          // four member rows in flight, added in member order
+                    float xv[4], wv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const bool have = m != 0;
+                        const int j = have ? __builtin_ctzll(m) : 0;
+                        m &= m - 1;                                  // stays 0 once exhausted
+                        const int64_t rj = readlane_i64(row, j);
+                        wv[u] = have ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(wn), j)) : 0.f;
+                        xv[u] = (have && c < D) ? x[rj * D + c] : 1.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) acc += xv[u] * wv[u];
                 }
                 if (c < D1) atomicAdd(dst + c, acc);
             }
