@@ -24,6 +24,7 @@
 namespace c3dgs {
 
 constexpr int BATCH = 256;
+constexpr int REC_F2 = 5;   // a staged splat record in LDS: 5 x float2 = 40 bytes, 8-byte aligned
 
 // alpha of one Gaussian at one pixel; the SAME instruction sequence in forward and backward so both
 // take identical skip decisions (explicit fma placement, independent of -ffp-contract).
@@ -124,14 +125,17 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
 {
     const int tile = tile_of_block(blockIdx.x, T);
     if (tile >= T || (blockIdx.x >> 3) >= ((T + 7) >> 3)) return;
-    // a and b halves of an entry side by side: one address register serves both reads (the buffer index is a run-time
-    // value, so two arrays would need two). Entry BATCH of each buffer: sentinel with opacity 0 (blends nothing)
-    __shared__ float4 s_ab[2][BATCH + 1][2];
-    __shared__ float s_c[2][BATCH + 1];
-    __shared__ uint16_t s_list[4][(BATCH / 8 + 2) * 8];   // per wave: its candidates of the batch, 8 per 16-byte row
+    // A staged entry is a 40-byte record {x, y, conic a, b | conic c, opacity, r, g | b, -}. The candidate lists hold the
+    // records' BYTE OFFSETS inside s_rec, so a list word read back from LDS is the address operand of the three record reads
+    // (two ds_read2_b64, one ds_read_b32) as it is: no scalar unpacking, no address arithmetic, no v_mov per Gaussian (the
+    // blend loop is VALU-issue bound: -3.5 of ~29 vector instructions per (wave, Gaussian) pair). Entry BATCH of each
+    // buffer: sentinel with opacity 0 (blends nothing).
+    __shared__ float2 s_rec[2][BATCH + 1][REC_F2];
+    __shared__ uint32_t s_list[4][BATCH + 8];        // per wave: its candidates of the batch, padded to a multiple of 8
     __shared__ int s_wdone[2][4];
     __shared__ unsigned long long s_mask[2][4][4];   // [buf][quadrant][staging wave]: which staged Gaussians reach it
     __shared__ uint32_t s_used;
+    constexpr uint32_t REC_BYTES = REC_F2 * 8, BUF_BYTES = (BATCH + 1) * REC_BYTES;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = tile % gx, ty = tile / gx;
@@ -141,7 +145,9 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     const float pxf = (float)px, pyf = (float)py;
     bool done = !inside;
     if (tid == 0) s_used = 0;
-    if (tid < 2) { s_ab[tid][BATCH][0] = make_float4(0, 0, 0, 0); s_ab[tid][BATCH][1] = make_float4(0, 0, 0, 0); s_c[tid][BATCH] = 0.f; }
+    if (tid < 2)
+#pragma unroll
+        for (int q = 0; q < REC_F2; q++) s_rec[tid][BATCH][q] = make_float2(0.f, 0.f);
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
     const uint2 range = ranges[tile];
@@ -150,6 +156,8 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
 
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_contributor = 0;
+    constexpr uint32_t NO_ENTRY = 0xffffffffu;
+    const char* rec_base = reinterpret_cast<const char*>(&s_rec[0][0][0]);
 
     float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
     if (tid < n) {
@@ -158,7 +166,9 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     }
     for (int r = 0; r < rounds; r++) {
         const int buf = r & 1;
-        s_ab[buf][tid][0] = ra; s_ab[buf][tid][1] = rb; s_c[buf][tid] = rc.x;
+        s_rec[buf][tid][0] = make_float2(ra.x, ra.y); s_rec[buf][tid][1] = make_float2(ra.z, ra.w);
+        s_rec[buf][tid][2] = make_float2(rb.x, rb.y); s_rec[buf][tid][3] = make_float2(rb.z, rb.w);
+        s_rec[buf][tid][4] = make_float2(rc.x, 0.f);
         const uint32_t qm = (r * BATCH + tid < n) ? quadrant_mask(ra, rb, tile_x0, tile_y0) : 0u;
         if (r * BATCH + tid < n) qmask[range.x + r * BATCH + tid] = (uint8_t)qm;   // the backward reuses it (same test, ~100 VALU ops)
 #pragma unroll
@@ -176,35 +186,37 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
             ra = splat[3 * (size_t)id]; rb = splat[3 * (size_t)id + 1]; rc = splat[3 * (size_t)id + 2];
         }
         if (wave_done) continue;
-        const uint32_t base = (uint32_t)(r * BATCH);
-        // This wave's candidates of the batch, compacted into LDS once (8 entry indices per 16-byte row, padded with the
-        // sentinel): the blend loop then needs no bit scanning and no per-Gaussian scalar control flow.
+        // This wave's candidates of the batch, compacted into LDS once (record offsets, padded with the sentinel's to a
+        // multiple of 8): the blend loop then needs no bit scanning and no per-Gaussian scalar control flow.
         int nw = 0;
         {
             const unsigned long long lt = (1ull << lane) - 1ull;
+            const uint32_t buf_off = (uint32_t)buf * BUF_BYTES;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const unsigned long long m = uniform_u64(s_mask[buf][wave][c]);   // Gaussians that can reach this quadrant
-                if ((m >> lane) & 1ull) s_list[wave][nw + (int)__popcll(m & lt)] = (uint16_t)(c * 64 + lane);
+                if ((m >> lane) & 1ull) s_list[wave][nw + (int)__popcll(m & lt)] = buf_off + (uint32_t)(c * 64 + lane) * REC_BYTES;
                 nw += (int)__popcll(m);
             }
-            if (lane < 8) s_list[wave][nw + lane] = (uint16_t)BATCH;
+            if (lane < 8) s_list[wave][nw + lane] = buf_off + (uint32_t)BATCH * REC_BYTES;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        uint32_t last_off = NO_ENTRY;                    // record offset of the last Gaussian this pixel blended in this batch
         for (int k = 0; k < nw; k += 8) {
             // the wave's early-out is tested once per row of 8, not per Gaussian: finished pixels blend nothing either
             // way, and a per-Gaussian test (ballot + scalar branch) costs more than the work it saves
             if (__all(done)) break;
-            const uint4 row = *reinterpret_cast<const uint4*>(&s_list[wave][k]);
-            const uint32_t rw[4] = { (uint32_t)__builtin_amdgcn_readfirstlane((int)row.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)row.y),
-                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)row.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)row.w) };
+            const uint4 row0 = *reinterpret_cast<const uint4*>(&s_list[wave][k]);
+            const uint4 row1 = *reinterpret_cast<const uint4*>(&s_list[wave][k + 4]);
+            const uint32_t e[8] = { row0.x, row0.y, row0.z, row0.w, row1.x, row1.y, row1.z, row1.w };
 #pragma unroll
             for (int g = 0; g < 8; g++) {
-                const int j = (int)((rw[g >> 1] >> ((g & 1) * 16)) & 0xffffu);
-                const float4 a = s_ab[buf][j][0], b = s_ab[buf][j][1];
-                const float cblue = s_c[buf][j];
+                const float2* rp = reinterpret_cast<const float2*>(rec_base + e[g]);
+                const float2 a0 = rp[0], a1 = rp[1], b0 = rp[2], b1 = rp[3];
+                const float4 a = make_float4(a0.x, a0.y, a1.x, a1.y), b = make_float4(b0.x, b0.y, b1.x, b1.y);
+                const float cblue = *reinterpret_cast<const float*>(rec_base + e[g] + 32);
                 float dx, dy, G, alpha;
                 const bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
                 // branch-free blend (selects instead of nested exec-mask regions)
@@ -215,10 +227,13 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
                 const float w = blend ? alpha * Tr : 0.f;
                 C0 = fmaf(b.z, w, C0); C1 = fmaf(b.w, w, C1); C2 = fmaf(cblue, w, C2);
                 Tr = blend ? test_T : Tr;
-                last_contributor = blend ? base + (uint32_t)j + 1u : last_contributor;
+                last_off = blend ? e[g] : last_off;
                 done = done || stop;
             }
         }
+        // offset -> 1-based position in the tile's list (once per batch, not per Gaussian); x / 40 == (x * 52429) >> 21 below 2^15
+        if (last_off != NO_ENTRY)
+            last_contributor = (uint32_t)(r * BATCH) + (((last_off - (uint32_t)buf * BUF_BYTES) * 52429u) >> 21) + 1u;
     }
     if (inside) {
         const size_t pix = (size_t)W * py + px, HW = (size_t)H * W;
@@ -340,13 +355,16 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     // longest tiles first (tile_order: descending tile_used), so that the last workgroups to start are the short ones
     if ((int)blockIdx.x >= T) return;
     const int tile = (int)tile_order[blockIdx.x];
-    __shared__ float4 s_a[BATCH + 1];                 // entry BATCH is a sentinel with opacity 0 (blends nothing)
-    __shared__ float4 s_b[BATCH + 1];
-    __shared__ float s_c[BATCH + 1];
-    __shared__ uint32_t s_slot[BATCH];
-    __shared__ uint16_t s_list[4][(BATCH / GROUP_G + 2) * 8];   // per wave: its candidates of the batch, 7 per 16-byte row
+    // staged entries: the forward's 40-byte record with the instance's backward slot in the spare word; the candidate lists
+    // hold record BYTE OFFSETS that feed the LDS reads directly (see render_forward_kernel). Entry BATCH: sentinel, opacity 0.
+    __shared__ float2 s_rec[BATCH + 1][REC_F2];
+    // per wave: its candidates of HALF a batch (128 entries) at a time, 7 per 32-byte row (one row = one reduction group);
+    // half batches keep the kernel's LDS at 31 KB = five workgroups per CU
+    __shared__ uint32_t s_list[4][(BATCH / 2 / GROUP_G + 2) * 8];
     __shared__ unsigned long long s_mask[4][4];      // [quadrant][staging wave]
     __shared__ float s_part[2][BATCH][NPART];         // one plane per wave PAIR (see the flush below)
+    constexpr uint32_t REC_BYTES = REC_F2 * 8;
+    const char* rec_base = reinterpret_cast<const char*>(&s_rec[0][0]);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = tile % gx, ty = tile / gx;
@@ -361,7 +379,9 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     const int used = min(n, (int)tile_used[tile]);
     if (used <= 0) return;
     const int rounds = (used + BATCH - 1) / BATCH;
-    if (tid == 0) { s_a[BATCH] = make_float4(0, 0, 0, 0); s_b[BATCH] = make_float4(0, 0, 0, 0); s_c[BATCH] = 0.f; }
+    if (tid == 0)
+#pragma unroll
+        for (int q = 0; q < REC_F2; q++) s_rec[BATCH][q] = make_float2(0.f, 0.f);
 
     const float T_final = inside ? final_Ts[pix] : 0.f;         // backward.cu:441-447
     float Tr = T_final;
@@ -390,10 +410,12 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
         if (mypos >= 0) {
             const uint32_t id = point_list[range.x + mypos];
             const float4 a = splat[3 * (size_t)id], b = splat[3 * (size_t)id + 1], c = splat[3 * (size_t)id + 2];
-            s_a[tid] = a; s_b[tid] = b; s_c[tid] = c.x;
             const uint32_t off = __float_as_uint(c.y), lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
             const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
-            s_slot[tid] = block_base[id >> 8] + off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            const uint32_t slot = block_base[id >> 8] + off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            s_rec[tid][0] = make_float2(a.x, a.y); s_rec[tid][1] = make_float2(a.z, a.w);
+            s_rec[tid][2] = make_float2(b.x, b.y); s_rec[tid][3] = make_float2(b.z, b.w);
+            s_rec[tid][4] = make_float2(c.x, __uint_as_float(slot));
             qm = qmask[range.x + mypos];                          // written by the forward for every entry it staged
         }
 #pragma unroll
@@ -409,47 +431,53 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
 
         const int cnt = min(BATCH, used - r * BATCH);
         const int pos0 = used - 1 - r * BATCH;                   // position of batch entry j is pos0 - j
-        // This wave's candidates of the batch, compacted into LDS once: 7 entry indices per 16-byte row (one row = one
-        // reduction group), padded with the sentinel. The group loop below then has NO data-dependent control flow: one
-        // broadcast row read, seven fixed slots, one reduction. (A slot whose Gaussian turns out to touch no pixel of the
-        // wave -- 3.6 % on the bench scene -- adds zeros; testing for it per Gaussian cost more than it saved.)
+        // a pixel blends entry j only if pos0 - j < last_contributor (backward.cu:486-488), i.e. record offset > thr
+        const int thr = (pos0 - last_contributor) * (int)REC_BYTES;
+        // This wave's candidates, compacted into LDS: 7 record offsets per 32-byte row (one row = one reduction group),
+        // padded with the sentinel's. The group loop below then has NO data-dependent control flow: one broadcast row read,
+        // seven fixed slots, one reduction. (A slot whose Gaussian turns out to touch no pixel of the wave -- 3.6 % on the
+        // bench scene -- adds zeros; testing for it per Gaussian cost more than it saved.)
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
         int nw = 0;
         {
             const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
+            for (int cc = 0; cc < 2; cc++) {
+                const int c = half * 2 + cc;
                 unsigned long long m = uniform_u64(s_mask[wave][c]);
                 // entries with pos >= wave_last (j <= pos0 - wave_last) are behind every pixel of this wave
                 const int jmin = pos0 - wave_last + 1 - c * 64;
                 if (jmin >= 64) m = 0; else if (jmin > 0) m &= ~0ull << jmin;
                 if ((m >> lane) & 1ull) {
                     const int p = nw + (int)__popcll(m & lt), row = p / GROUP_G;
-                    s_list[wave][row * 8 + (p - row * GROUP_G)] = (uint16_t)(c * 64 + lane);
+                    s_list[wave][row * 8 + (p - row * GROUP_G)] = (uint32_t)(c * 64 + lane) * REC_BYTES;
                 }
                 nw += (int)__popcll(m);
             }
             if (lane < GROUP_G) {
                 const int p = nw + lane, row = p / GROUP_G;
-                s_list[wave][row * 8 + (p - row * GROUP_G)] = (uint16_t)BATCH;
+                s_list[wave][row * 8 + (p - row * GROUP_G)] = (uint32_t)BATCH * REC_BYTES;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         for (int k = 0; k < nw; k += GROUP_G) {
-            const uint4 row = *reinterpret_cast<const uint4*>(&s_list[wave][(k / GROUP_G) * 8]);
-            const uint32_t rw[4] = { (uint32_t)__builtin_amdgcn_readfirstlane((int)row.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)row.y),
-                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)row.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)row.w) };
+            const uint32_t* lrow = &s_list[wave][(k / GROUP_G) * 8];
+            const uint4 row0 = *reinterpret_cast<const uint4*>(lrow);
+            const uint4 row1 = *reinterpret_cast<const uint4*>(lrow + 4);
+            const uint32_t e[GROUP_G] = { row0.x, row0.y, row0.z, row0.w, row1.x, row1.y, row1.z };
             float v[64];
             v[63] = 0.f;                                         // pad: 7 x 9 = 63 values
 #pragma unroll
             for (int g = 0; g < GROUP_G; g++) {
-                const int j = (int)((rw[g >> 1] >> ((g & 1) * 16)) & 0xffffu);
-                const int pos = pos0 - j;                        // 0-based position in the tile's list
-                const float4 a = s_a[j], b = s_b[j];
+                const float2* rp = reinterpret_cast<const float2*>(rec_base + e[g]);
+                const float2 a0 = rp[0], a1 = rp[1], b0 = rp[2], b1 = rp[3];
+                const float cblue = *reinterpret_cast<const float*>(rec_base + e[g] + 32);
                 float dx, dy, G, alpha;
-                bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
-                hit = hit && (pos < last_contributor);           // backward.cu:486-488
+                bool hit = gaussian_alpha(a0.x, a0.y, a1.x, a1.y, b0.x, b0.y, pxf, pyf, dx, dy, G, alpha);
+                hit = hit && ((int)e[g] > thr);                  // backward.cu:486-488
                 // branch-free: a pixel that does not blend this Gaussian runs the same instructions with
                 // alpha = G = 0, which leaves T and Sd untouched and makes all nine terms exactly 0
                 const float a_eff = hit ? alpha : 0.f, G_eff = hit ? G : 0.f;
@@ -457,7 +485,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                 const float rinv = __builtin_amdgcn_rcpf(1.f - a_eff);
                 Tr = Tr * rinv;                                  // transmittance in front of this Gaussian
                 const float dchannel_dcolor = a_eff * Tr;
-                const float cd = fmaf(s_c[j], dpx2, fmaf(b.w, dpx1, b.z * dpx0));
+                const float cd = fmaf(cblue, dpx2, fmaf(b1.y, dpx1, b1.x * dpx0));
                 v[g * NPART + 0] = dchannel_dcolor * dpx0;
                 v[g * NPART + 1] = dchannel_dcolor * dpx1;
                 v[g * NPART + 2] = dchannel_dcolor * dpx2;
@@ -477,19 +505,24 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             }
             const float total = transpose_reduce_64(v, lane);
             // batch entry of the group slot this lane's reduced value belongs to (slot 7 of a row is padding: my_idx 63)
-            const int myj = (int)s_list[wave][(k / GROUP_G) * 8 + my_g];
+            const uint32_t my_off = lrow[my_g];
+            const int myj = (int)((my_off * 52429u) >> 21);      // offset / 40
             // LDS float add into the plane this wave shares with ONE other wave: every (entry, term) receives at most
             // one add per wave, and a + b == b + a, so the result does not depend on which wave arrives first
             if (my_idx < GROUP_G * NPART && myj < BATCH)
                 __hip_atomic_fetch_add(&s_part[wave >> 1][myj][my_c], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the list is rebuilt for the second half
+        __builtin_amdgcn_wave_barrier();
+        }
         __syncthreads();
         if (tid < cnt) {
-            float* dst = partials + (size_t)s_slot[tid] * NPART;
+            const uint32_t slot = __float_as_uint(s_rec[tid][4].y);
+            float* dst = partials + (size_t)slot * NPART;
 #pragma unroll
             for (int q = 0; q < NPART; q++)
                 dst[q] = s_part[0][tid][q] + s_part[1][tid][q];      // (w0 + w1) + (w2 + w3): fixed order, reproducible
-            touched[s_slot[tid]] = 1;
+            touched[slot] = 1;
         }
     }
 }

@@ -508,6 +508,18 @@ vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * 256) >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // second merge level, across the workgroup's waves: group sums of SHARED codewords go to a small direct-mapped table in
+    // LDS first (slot = codeword & 31, claimed by compare-and-swap; a codeword that finds its slot taken by another one adds
+    // to global memory directly) and reach global memory once per workgroup
+    constexpr int SLOTS = 32;
+    __shared__ int s_tag[SLOTS];
+    __shared__ float s_sum[SLOTS][64];
+    const bool use_slots = D1 <= 64;
+    if (use_slots) {
+        for (int q = threadIdx.x; q < SLOTS * 64; q += 256) (&s_sum[0][0])[q] = 0.f;
+        if (threadIdx.x < SLOTS) s_tag[threadIdx.x] = -1;
+    }
+    __syncthreads();
     for (int64_t base = wave_id * 64; base < B; base += n_waves * 64) {
         const int64_t n = base + lane;
         const bool valid = n < B;
@@ -526,12 +538,14 @@ vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x
             // elements are added densely, 64 consecutive elements per instruction (every lane busy; a point's D+1 atomics
             // stay contiguous)
             const int total = (int)__popcll(leaders) * D1;
-            for (int e = lane; e < total; e += 64) {
-                const int j = e / D1, c = e - j * D1;
-                const int64_t nj = base + j;
-                const int64_t rj = gather ? gather[nj] : nj;
-                const float wj = w[rj];
-                atomicAdd(S + (size_t)idx[nj] * D1 + c, c < D ? x[rj * D + c] * wj : wj);
+            const uint32_t row_lo = (uint32_t)row, row_hi = (uint32_t)((uint64_t)row >> 32);
+#pragma unroll 7
+            for (int e = lane; e < total; e += 64) {                 // the point's row / weight / codeword come from the lane
+                const int j = e / D1, c = e - j * D1;                // that already holds them (no dependent global loads)
+                const int64_t rj = (int64_t)(((uint64_t)(uint32_t)__shfl((int)row_hi, j) << 32) | (uint32_t)__shfl((int)row_lo, j));
+                const float wj = __shfl(wn, j);
+                const uint32_t idj = (uint32_t)__shfl((int)id, j);
+                atomicAdd(S + (size_t)idj * D1 + c, c < D ? x[rj * D + c] * wj : wj);
             }
             continue;
         }
@@ -541,7 +555,14 @@ vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x
             const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)peers, l);
             const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(peers >> 32), l);
             unsigned long long members = ((unsigned long long)phi << 32) | plo;
-            float* dst = S + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)id, l) * D1;
+            const int gid = __builtin_amdgcn_readlane((int)id, l);
+            float* dst = S + (size_t)(uint32_t)gid * D1;
+            if (use_slots) {
+                int owner = 0;
+                if (lane == 0) owner = atomicCAS(&s_tag[gid & (SLOTS - 1)], -1, gid);
+                owner = __builtin_amdgcn_readfirstlane(owner);
+                if (owner == -1 || owner == gid) dst = nullptr;      // this workgroup's slot of the codeword
+            }
             for (int c0 = 0; c0 < D1; c0 += 64) {                    // D + 1 <= 64 for every codebook of the pipeline: one pass
                 const int c = c0 + lane;
                 float acc = 0.f;
@@ -560,8 +581,18 @@ vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x
 #pragma unroll
                     for (int u = 0; u < 4; u++) acc += xv[u] * wv[u];
                 }
-                if (c < D1) atomicAdd(dst + c, acc);
+                if (c < D1) {
+                    if (dst) atomicAdd(dst + c, acc);
+                    else __hip_atomic_fetch_add(&s_sum[gid & (SLOTS - 1)][c], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
+        }
+    }
+    if (use_slots) {
+        __syncthreads();
+        for (int sl = threadIdx.x >> 6; sl < SLOTS; sl += 4) {
+            const int tag = s_tag[sl];
+            if (tag >= 0 && lane < D1) atomicAdd(S + (size_t)(uint32_t)tag * D1 + lane, s_sum[sl][lane]);
         }
     }
 }
