@@ -36,7 +36,7 @@ class RasterGrads(C.Structure):
 
 class GeomLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
-        "total_bytes", "splat", "depths", "tiles_touched", "depth_keys", "ids", "depth_keys_sorted", "depth_order",
+        "total_bytes", "splat", "depth_keys", "depth_keys_sorted", "depth_order",
         "sorted_offsets", "inst_offset", "rects", "clamped", "scan_temp", "scan_temp_bytes", "block_base", "depth_base")]
 
 

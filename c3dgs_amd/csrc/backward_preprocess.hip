@@ -29,7 +29,7 @@ struct BwdArgs {
     const float* cov3D_precomp; const int64_t* sh_indices; const int64_t* g_indices;
     const float* view; const float* proj; const float* campos;
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
-    const int32_t* radii; const uint32_t* tiles_touched; const uint32_t* inst_offset; const uint32_t* block_base; const uint8_t* clamped; const float4* splat;
+    const int32_t* radii; const uint32_t* inst_offset; const uint32_t* block_base; const uint8_t* clamped; const float4* splat;
     const float* partials; const uint8_t* touched;
     c3dgs_raster_grads g;
 };
@@ -469,7 +469,7 @@ void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* rad
     a.focal_y = p.H / (2.0f * p.tan_fovy);
     a.focal_x = p.W / (2.0f * p.tan_fovx);
     a.scale_modifier = p.scale_modifier;
-    a.radii = radii; a.tiles_touched = g.tiles_touched; a.inst_offset = g.inst_offset; a.block_base = g.block_base; a.clamped = g.clamped; a.splat = g.splat;
+    a.radii = radii; a.inst_offset = g.inst_offset; a.block_base = g.block_base; a.clamped = g.clamped; a.splat = g.splat;
     a.partials = partials; a.touched = touched; a.g = gr;
     const dim3 grid((p.P + 255) / 256), block(256);
     const bool indexed = p.sh_indices != nullptr || p.g_indices != nullptr;

@@ -15,6 +15,7 @@
 // (asserted against the oracle). (The umbrella <rocprim/rocprim.hpp> does not compile on this ROCm install.)
 #include "common.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 namespace c3dgs {
 
@@ -57,7 +58,10 @@ hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, ui
 {
     if (onesweep_enabled() && (size_t)P < ((size_t)1 << 30))
         return onesweep_depth_sort(temp, temp_bytes, kin, kout, vin, vout, P, rects, rects_sorted, s);
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 0u, 32u, s);
+    // vin == nullptr: the payload is the Gaussian id itself (0 .. P-1)
+    hipError_t e = vin ? rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 0u, 32u, s)
+                       : rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, rocprim::counting_iterator<uint32_t>(0u), vout,
+                                                   (size_t)P, 0u, 32u, s);
     if (e != hipSuccess) return e;
     gather_u64_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, vout, rects, rects_sorted);
     return hipGetLastError();

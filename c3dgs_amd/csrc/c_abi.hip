@@ -144,7 +144,7 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     C3DGS_HIP_TRY(hipMemcpyAsync(hr.pinned, g.block_base + (P + 255) / 256, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     C3DGS_HIP_TRY(hipEventRecord(hr.ev, s));
     { StageTimer t_(ST_DEPTH_SORT, s);                                               // binning stage 1: P Gaussians by depth
-      C3DGS_HIP_TRY(run_depth_sort(g.scan_temp, g.scan_temp_bytes, g.depth_keys, g.depth_keys_sorted, g.ids, g.depth_order, P,
+      C3DGS_HIP_TRY(run_depth_sort(g.scan_temp, g.scan_temp_bytes, g.depth_keys, g.depth_keys_sorted, nullptr, g.depth_order, P,
                                    reinterpret_cast<const uint2*>(g.rects), g.sorted_offsets, s)); }
     C3DGS_STAGE("depth_sort", p.debug, s);
     if (p.debug && onesweep_timed_out(s)) return fail(C3DGS_E_HIP, "depth sort: look-back timed out");

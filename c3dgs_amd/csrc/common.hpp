@@ -62,10 +62,7 @@ inline void geom_layout(int P, c3dgs_geom_layout* L)
 {
     size_t o = 0, p = (size_t)(P > 0 ? P : 1);
     L->splat = o;             o = align_up(o + p * SPLAT_F4 * 16);
-    L->depths = o;            o = align_up(o + p * 4);
-    L->tiles_touched = o;     o = align_up(o + p * 4);
     L->depth_keys = o;        o = align_up(o + p * 4);
-    L->ids = o;               o = align_up(o + p * 4);
     L->depth_keys_sorted = o; o = align_up(o + p * 4);
     L->depth_order = o;       o = align_up(o + p * 4);
     L->sorted_offsets = o;    o = align_up(o + p * 8);
@@ -104,7 +101,7 @@ inline void image_layout(int W, int H, c3dgs_image_layout* L)
 
 // ---------------------------------------------------------------- kernel launchers (one per .hip file)
 struct GeomPtrs {
-    float4* splat; float* depths; uint32_t* tiles_touched; uint32_t* depth_keys; uint32_t* ids; uint32_t* depth_keys_sorted;
+    float4* splat; uint32_t* depth_keys; uint32_t* depth_keys_sorted;
     uint32_t* depth_order; uint2* sorted_offsets; uint32_t* inst_offset; uint16_t* rects;
     uint8_t* clamped; uint32_t* block_base; uint32_t* depth_base; void* scan_temp; size_t scan_temp_bytes;
 };
@@ -118,8 +115,7 @@ inline GeomPtrs geom_ptrs(void* base, int P)
 {
     c3dgs_geom_layout L; geom_layout(P, &L);
     char* b = (char*)base;
-    return { (float4*)(b + L.splat), (float*)(b + L.depths), (uint32_t*)(b + L.tiles_touched), (uint32_t*)(b + L.depth_keys),
-             (uint32_t*)(b + L.ids), (uint32_t*)(b + L.depth_keys_sorted), (uint32_t*)(b + L.depth_order),
+    return { (float4*)(b + L.splat), (uint32_t*)(b + L.depth_keys), (uint32_t*)(b + L.depth_keys_sorted), (uint32_t*)(b + L.depth_order),
              (uint2*)(b + L.sorted_offsets), (uint32_t*)(b + L.inst_offset), (uint16_t*)(b + L.rects),
              (uint8_t*)(b + L.clamped), (uint32_t*)(b + L.block_base), (uint32_t*)(b + L.depth_base), (void*)(b + L.scan_temp),
              L.scan_temp_bytes };

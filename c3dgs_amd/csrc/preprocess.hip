@@ -117,8 +117,8 @@ struct PreArgs {
     const float* view; const float* proj; const float* campos;
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     int prefiltered, clamp_color;
-    int32_t* radii; float4* splat; float* depths; uint32_t* tiles_touched; uint16_t* rects; uint8_t* clamped;
-    uint32_t* depth_keys; uint32_t* ids;
+    int32_t* radii; float4* splat; uint16_t* rects; uint8_t* clamped;
+    uint32_t* depth_keys;
     uint32_t* inst_offset; uint32_t* block_total;   // two-level id-order scan
     uint2* ranges; int T;                            // tile ranges, cleared here for identify_ranges (K7)
 };
@@ -221,7 +221,6 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
         out_radius = (int32_t)my_radius;
         out_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
         out_key = __float_as_uint(p_view.z);
-        a.depths[i] = p_view.z;
         a.clamped[i] = clamp_bits;
         uint16_t* rc = a.rects + 4 * (size_t)i;
         rc[0] = (uint16_t)x0; rc[1] = (uint16_t)y0; rc[2] = (uint16_t)x1; rc[3] = (uint16_t)y1;
@@ -253,9 +252,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
     }
     a.inst_offset[i] = my_incl;
     a.radii[i] = out_radius;
-    a.tiles_touched[i] = out_tiles;
     a.depth_keys[i] = out_key;
-    a.ids[i] = (uint32_t)i;
 }
 
 // exclusive scan of the workgroup totals, in place: base[b] = instances of all Gaussians before workgroup b;
@@ -301,8 +298,8 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
     a.focal_y = p.H / (2.0f * p.tan_fovy);                       // rasterizer_impl.cu:219-220
     a.focal_x = p.W / (2.0f * p.tan_fovx);
     a.scale_modifier = p.scale_modifier; a.prefiltered = p.prefiltered; a.clamp_color = p.clamp_color;
-    a.radii = radii; a.splat = g.splat; a.depths = g.depths; a.tiles_touched = g.tiles_touched; a.rects = g.rects;
-    a.clamped = g.clamped; a.depth_keys = g.depth_keys; a.ids = g.ids;
+    a.radii = radii; a.splat = g.splat; a.rects = g.rects;
+    a.clamped = g.clamped; a.depth_keys = g.depth_keys;
     a.inst_offset = g.inst_offset;
     a.block_total = g.block_base;     // totals in, exclusive bases out (scan_blocks_kernel)
     a.ranges = ranges; a.T = a.gx * a.gy;

@@ -154,7 +154,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
         const uint32_t idx = wbase + (uint32_t)k * 64u + lane;
         const bool ok = idx < n;
         key[k] = ok ? kin[idx] : (K)0;
-        val[k] = ok ? vin[idx] : 0u;
+        val[k] = ok ? (vin ? vin[idx] : idx) : 0u;             // no payload array: the payload is the item's index
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
     volatile uint32_t* wc = s_cnt[wave];              // other lanes of the wave update these between iterations

@@ -539,7 +539,6 @@ vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x
             // stay contiguous)
             const int total = (int)__popcll(leaders) * D1;
             const uint32_t row_lo = (uint32_t)row, row_hi = (uint32_t)((uint64_t)row >> 32);
-#pragma unroll 7
             for (int e = lane; e < total; e += 64) {                 // the point's row / weight / codeword come from the lane
                 const int j = e / D1, c = e - j * D1;                // that already holds them (no dependent global loads)
                 const int64_t rj = (int64_t)(((uint64_t)(uint32_t)__shfl((int)row_hi, j) << 32) | (uint32_t)__shfl((int)row_lo, j));

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define C3DGS_ABI_VERSION 1
+#define C3DGS_ABI_VERSION 2
 
 enum {
     C3DGS_OK = 0,
@@ -301,10 +301,8 @@ int c3dgs_fake_quantize_backward(int64_t n, const float* x, const c3dgs_fq_state
 typedef struct c3dgs_geom_layout {   /* byte offsets into the geometry buffer for P Gaussians */
     size_t total_bytes;
     size_t splat;          /* float4[3*P]: {x, y, conic_a, conic_b} {conic_c, opacity, r, g} {b, bits(instance offset), bits(rect_lo), bits(rect_hi)} */
-    size_t depths;         /* float[P]                                                     */
-    size_t tiles_touched;  /* uint32[P]                                                    */
-    size_t depth_keys;     /* uint32[P] depth bits, 0xFFFFFFFF for culled Gaussians        */
-    size_t ids;            /* uint32[P] 0..P-1 (sort payload in)                           */
+    size_t depth_keys;     /* uint32[P] bits of the view-space depth (the float itself for a visible Gaussian), 0xFFFFFFFF for
+                            * culled ones; tiles_touched is the area of `rects`; the sort payload is the Gaussian id itself  */
     size_t depth_keys_sorted; /* uint32[P]                                                 */
     size_t depth_order;    /* uint32[P] Gaussian ids in (depth, id) order                  */
     size_t sorted_offsets; /* uint16[4*P] tile rectangles in DEPTH order (k-th nearest Gaussian); their areas scanned with depth_base[k>>8] give the emission offsets */

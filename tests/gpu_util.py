@@ -82,8 +82,10 @@ def unpack(fw):
         out["means2D"] = splat[:, 0:2].copy()
         out["conic_opacity"] = np.stack([splat[:, 2], splat[:, 3], splat[:, 4], splat[:, 5]], 1)
         out["rgb"] = np.stack([splat[:, 6], splat[:, 7], splat[:, 8]], 1)
-        out["depths"] = _view(geom, gl.depths, P, torch.float32).cpu().numpy()
-        out["tiles_touched"] = _view(geom, gl.tiles_touched, P, torch.int32).cpu().numpy().view(np.uint32)
+        # depth_keys = bits of the view-space depth for visible Gaussians (0xFFFFFFFF = culled); tiles_touched = rect area
+        out["depths"] = _view(geom, gl.depth_keys, P, torch.float32).cpu().numpy()
+        rects = _view(geom, gl.rects, 4 * P, torch.int16).cpu().numpy().view(np.uint16).reshape(P, 4).astype(np.int64)
+        out["tiles_touched"] = ((rects[:, 2] - rects[:, 0]) * (rects[:, 3] - rects[:, 1])).astype(np.uint32)
         out["depth_order"] = _view(geom, gl.depth_order, P, torch.int32).cpu().numpy().view(np.uint32)
         out["inst_offset"] = _view(geom, gl.inst_offset, P, torch.int32).cpu().numpy().view(np.uint32)
         cl = _view(geom, gl.clamped, P, torch.uint8).cpu().numpy()

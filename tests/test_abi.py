@@ -29,17 +29,17 @@ def test_every_declared_symbol_is_exported_and_bound(L):
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/c3dgs_hip.h but not exported"
         assert s in _lib.PROTOTYPES, f"{s} has no ctypes prototype"
-    assert L.c3dgs_abi_version() == 1
+    assert L.c3dgs_abi_version() == 2
 
 
 def test_layouts_are_consistent(L):
     from c3dgs_amd import _lib
     g = _lib.GeomLayout()
     assert L.c3dgs_get_geom_layout(1000, C.byref(g)) == 0
-    offs = [g.splat, g.depths, g.tiles_touched, g.depth_keys, g.ids, g.depth_keys_sorted, g.depth_order, g.sorted_offsets,
+    offs = [g.splat, g.depth_keys, g.depth_keys_sorted, g.depth_order, g.sorted_offsets,
             g.inst_offset, g.rects, g.clamped, g.scan_temp]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs) and g.total_bytes > g.scan_temp
-    assert g.depths - g.splat >= 1000 * 48
+    assert g.depth_keys - g.splat >= 1000 * 48
     b = _lib.BinningLayout()
     assert L.c3dgs_get_binning_layout(5000, 1920, 1080, C.byref(b)) == 0
     assert b.values_unsorted - b.keys_unsorted >= 5000 * 2 and b.total_bytes > b.sort_temp
