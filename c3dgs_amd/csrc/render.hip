@@ -24,7 +24,6 @@
 namespace c3dgs {
 
 constexpr int BATCH = 256;
-constexpr int REC_F2 = 5;   // a staged splat record in LDS: 5 x float2 = 40 bytes, 8-byte aligned
 
 // alpha of one Gaussian at one pixel; the SAME instruction sequence in forward and backward so both
 // take identical skip decisions (explicit fma placement, independent of -ffp-contract).
@@ -125,17 +124,18 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
 {
     const int tile = tile_of_block(blockIdx.x, T);
     if (tile >= T || (blockIdx.x >> 3) >= ((T + 7) >> 3)) return;
-    // A staged entry is a 40-byte record {x, y, conic a, b | conic c, opacity, r, g | b, -}. The candidate lists hold the
-    // records' BYTE OFFSETS inside s_rec, so a list word read back from LDS is the address operand of the three record reads
-    // (two ds_read2_b64, one ds_read_b32) as it is: no scalar unpacking, no address arithmetic, no v_mov per Gaussian (the
-    // blend loop is VALU-issue bound: -3.5 of ~29 vector instructions per (wave, Gaussian) pair). Entry BATCH of each
-    // buffer: sentinel with opacity 0 (blends nothing).
-    __shared__ float2 s_rec[2][BATCH + 1][REC_F2];
+    // A staged entry is a 32-byte record {x, y, conic a, b | conic c, opacity, r, g} plus its blue in a second array. The
+    // candidate lists hold the records' BYTE OFFSETS inside s_ab, so a list word read back from LDS is the address operand
+    // of the two ds_read_b128 as it is (the blue's address is that offset >> 3): no scalar unpacking, no readfirstlane, one
+    // shift per Gaussian instead of three v_mov (the blend loop is VALU-issue bound). Entry BATCH of each buffer: sentinel
+    // with opacity 0 (blends nothing).
+    __shared__ float4 s_ab[2][BATCH + 1][2];
+    __shared__ float s_c[2][BATCH + 1];
     __shared__ uint32_t s_list[4][BATCH + 8];        // per wave: its candidates of the batch, padded to a multiple of 8
     __shared__ int s_wdone[2][4];
     __shared__ unsigned long long s_mask[2][4][4];   // [buf][quadrant][staging wave]: which staged Gaussians reach it
     __shared__ uint32_t s_used;
-    constexpr uint32_t REC_BYTES = REC_F2 * 8, BUF_BYTES = (BATCH + 1) * REC_BYTES;
+    constexpr uint32_t REC_BYTES = 32, BUF_BYTES = (BATCH + 1) * REC_BYTES;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = tile % gx, ty = tile / gx;
@@ -145,9 +145,7 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     const float pxf = (float)px, pyf = (float)py;
     bool done = !inside;
     if (tid == 0) s_used = 0;
-    if (tid < 2)
-#pragma unroll
-        for (int q = 0; q < REC_F2; q++) s_rec[tid][BATCH][q] = make_float2(0.f, 0.f);
+    if (tid < 2) { s_ab[tid][BATCH][0] = make_float4(0, 0, 0, 0); s_ab[tid][BATCH][1] = make_float4(0, 0, 0, 0); s_c[tid][BATCH] = 0.f; }
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
     const uint2 range = ranges[tile];
@@ -157,7 +155,8 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_contributor = 0;
     constexpr uint32_t NO_ENTRY = 0xffffffffu;
-    const char* rec_base = reinterpret_cast<const char*>(&s_rec[0][0][0]);
+    const char* rec_base = reinterpret_cast<const char*>(&s_ab[0][0][0]);
+    const char* blue_base = reinterpret_cast<const char*>(&s_c[0][0]);
 
     float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
     if (tid < n) {
@@ -166,9 +165,7 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     }
     for (int r = 0; r < rounds; r++) {
         const int buf = r & 1;
-        s_rec[buf][tid][0] = make_float2(ra.x, ra.y); s_rec[buf][tid][1] = make_float2(ra.z, ra.w);
-        s_rec[buf][tid][2] = make_float2(rb.x, rb.y); s_rec[buf][tid][3] = make_float2(rb.z, rb.w);
-        s_rec[buf][tid][4] = make_float2(rc.x, 0.f);
+        s_ab[buf][tid][0] = ra; s_ab[buf][tid][1] = rb; s_c[buf][tid] = rc.x;
         const uint32_t qm = (r * BATCH + tid < n) ? quadrant_mask(ra, rb, tile_x0, tile_y0) : 0u;
         if (r * BATCH + tid < n) qmask[range.x + r * BATCH + tid] = (uint8_t)qm;   // the backward reuses it (same test, ~100 VALU ops)
 #pragma unroll
@@ -213,10 +210,9 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
             const uint32_t e[8] = { row0.x, row0.y, row0.z, row0.w, row1.x, row1.y, row1.z, row1.w };
 #pragma unroll
             for (int g = 0; g < 8; g++) {
-                const float2* rp = reinterpret_cast<const float2*>(rec_base + e[g]);
-                const float2 a0 = rp[0], a1 = rp[1], b0 = rp[2], b1 = rp[3];
-                const float4 a = make_float4(a0.x, a0.y, a1.x, a1.y), b = make_float4(b0.x, b0.y, b1.x, b1.y);
-                const float cblue = *reinterpret_cast<const float*>(rec_base + e[g] + 32);
+                const float4 a = *reinterpret_cast<const float4*>(rec_base + e[g]);
+                const float4 b = *reinterpret_cast<const float4*>(rec_base + e[g] + 16);
+                const float cblue = *reinterpret_cast<const float*>(blue_base + (e[g] >> 3));   // 4-byte pitch = 32-byte pitch / 8
                 float dx, dy, G, alpha;
                 const bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
                 // branch-free blend (selects instead of nested exec-mask regions)
@@ -231,9 +227,8 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
                 done = done || stop;
             }
         }
-        // offset -> 1-based position in the tile's list (once per batch, not per Gaussian); x / 40 == (x * 52429) >> 21 below 2^15
-        if (last_off != NO_ENTRY)
-            last_contributor = (uint32_t)(r * BATCH) + (((last_off - (uint32_t)buf * BUF_BYTES) * 52429u) >> 21) + 1u;
+        // offset -> 1-based position in the tile's list (once per batch, not per Gaussian)
+        if (last_off != NO_ENTRY) last_contributor = (uint32_t)(r * BATCH) + ((last_off - (uint32_t)buf * BUF_BYTES) >> 5) + 1u;
     }
     if (inside) {
         const size_t pix = (size_t)W * py + px, HW = (size_t)H * W;
@@ -355,16 +350,20 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     // longest tiles first (tile_order: descending tile_used), so that the last workgroups to start are the short ones
     if ((int)blockIdx.x >= T) return;
     const int tile = (int)tile_order[blockIdx.x];
-    // staged entries: the forward's 40-byte record with the instance's backward slot in the spare word; the candidate lists
-    // hold record BYTE OFFSETS that feed the LDS reads directly (see render_forward_kernel). Entry BATCH: sentinel, opacity 0.
-    __shared__ float2 s_rec[BATCH + 1][REC_F2];
+    // staged entries as in the forward: 32-byte records {x, y, conic a, b | conic c, opacity, r, g}, blue and the instance's
+    // backward slot in arrays of their own; the candidate lists hold record BYTE OFFSETS that feed the LDS reads directly
+    // (see render_forward_kernel). Entry BATCH: sentinel, opacity 0.
+    __shared__ float4 s_ab[BATCH + 1][2];
+    __shared__ float s_c[BATCH + 1];
+    __shared__ uint32_t s_slot[BATCH];
     // per wave: its candidates of HALF a batch (128 entries) at a time, 7 per 32-byte row (one row = one reduction group);
     // half batches keep the kernel's LDS at 31 KB = five workgroups per CU
     __shared__ uint32_t s_list[4][(BATCH / 2 / GROUP_G + 2) * 8];
     __shared__ unsigned long long s_mask[4][4];      // [quadrant][staging wave]
     __shared__ float s_part[2][BATCH][NPART];         // one plane per wave PAIR (see the flush below)
-    constexpr uint32_t REC_BYTES = REC_F2 * 8;
-    const char* rec_base = reinterpret_cast<const char*>(&s_rec[0][0]);
+    constexpr uint32_t REC_BYTES = 32;
+    const char* rec_base = reinterpret_cast<const char*>(&s_ab[0][0]);
+    const char* blue_base = reinterpret_cast<const char*>(&s_c[0]);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = tile % gx, ty = tile / gx;
@@ -379,9 +378,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     const int used = min(n, (int)tile_used[tile]);
     if (used <= 0) return;
     const int rounds = (used + BATCH - 1) / BATCH;
-    if (tid == 0)
-#pragma unroll
-        for (int q = 0; q < REC_F2; q++) s_rec[BATCH][q] = make_float2(0.f, 0.f);
+    if (tid == 0) { s_ab[BATCH][0] = make_float4(0, 0, 0, 0); s_ab[BATCH][1] = make_float4(0, 0, 0, 0); s_c[BATCH] = 0.f; }
 
     const float T_final = inside ? final_Ts[pix] : 0.f;         // backward.cu:441-447
     float Tr = T_final;
@@ -412,10 +409,8 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             const float4 a = splat[3 * (size_t)id], b = splat[3 * (size_t)id + 1], c = splat[3 * (size_t)id + 2];
             const uint32_t off = __float_as_uint(c.y), lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
             const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
-            const uint32_t slot = block_base[id >> 8] + off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-            s_rec[tid][0] = make_float2(a.x, a.y); s_rec[tid][1] = make_float2(a.z, a.w);
-            s_rec[tid][2] = make_float2(b.x, b.y); s_rec[tid][3] = make_float2(b.z, b.w);
-            s_rec[tid][4] = make_float2(c.x, __uint_as_float(slot));
+            s_slot[tid] = block_base[id >> 8] + off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            s_ab[tid][0] = a; s_ab[tid][1] = b; s_c[tid] = c.x;
             qm = qmask[range.x + mypos];                          // written by the forward for every entry it staged
         }
 #pragma unroll
@@ -472,11 +467,11 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             v[63] = 0.f;                                         // pad: 7 x 9 = 63 values
 #pragma unroll
             for (int g = 0; g < GROUP_G; g++) {
-                const float2* rp = reinterpret_cast<const float2*>(rec_base + e[g]);
-                const float2 a0 = rp[0], a1 = rp[1], b0 = rp[2], b1 = rp[3];
-                const float cblue = *reinterpret_cast<const float*>(rec_base + e[g] + 32);
+                const float4 a = *reinterpret_cast<const float4*>(rec_base + e[g]);
+                const float4 b = *reinterpret_cast<const float4*>(rec_base + e[g] + 16);
+                const float cblue = *reinterpret_cast<const float*>(blue_base + (e[g] >> 3));
                 float dx, dy, G, alpha;
-                bool hit = gaussian_alpha(a0.x, a0.y, a1.x, a1.y, b0.x, b0.y, pxf, pyf, dx, dy, G, alpha);
+                bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
                 hit = hit && ((int)e[g] > thr);                  // backward.cu:486-488
                 // branch-free: a pixel that does not blend this Gaussian runs the same instructions with
                 // alpha = G = 0, which leaves T and Sd untouched and makes all nine terms exactly 0
@@ -485,7 +480,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                 const float rinv = __builtin_amdgcn_rcpf(1.f - a_eff);
                 Tr = Tr * rinv;                                  // transmittance in front of this Gaussian
                 const float dchannel_dcolor = a_eff * Tr;
-                const float cd = fmaf(cblue, dpx2, fmaf(b1.y, dpx1, b1.x * dpx0));
+                const float cd = fmaf(cblue, dpx2, fmaf(b.w, dpx1, b.z * dpx0));
                 v[g * NPART + 0] = dchannel_dcolor * dpx0;
                 v[g * NPART + 1] = dchannel_dcolor * dpx1;
                 v[g * NPART + 2] = dchannel_dcolor * dpx2;
@@ -506,7 +501,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             const float total = transpose_reduce_64(v, lane);
             // batch entry of the group slot this lane's reduced value belongs to (slot 7 of a row is padding: my_idx 63)
             const uint32_t my_off = lrow[my_g];
-            const int myj = (int)((my_off * 52429u) >> 21);      // offset / 40
+            const int myj = (int)(my_off >> 5);                  // offset / 32
             // LDS float add into the plane this wave shares with ONE other wave: every (entry, term) receives at most
             // one add per wave, and a + b == b + a, so the result does not depend on which wave arrives first
             if (my_idx < GROUP_G * NPART && myj < BATCH)
@@ -517,7 +512,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
         }
         __syncthreads();
         if (tid < cnt) {
-            const uint32_t slot = __float_as_uint(s_rec[tid][4].y);
+            const uint32_t slot = s_slot[tid];
             float* dst = partials + (size_t)slot * NPART;
 #pragma unroll
             for (int q = 0; q < NPART; q++)
