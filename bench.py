@@ -264,7 +264,9 @@ def main():
     bit = higher_msb(T)
     stage_ms = {k: v[0] / max(v[1], 1) for k, v in stages.items()}
     stage_ms[dom] = dom_live[dom][0] / max(dom_live[dom][1], 1)     # the timed region's own measurement
-    raster_stages = [k for k in stage_ms if k in raster_names and k != "depth_sort"]
+    # the view's algorithmic bytes are those of the REFERENCE's algorithm, whatever stages this build fuses away
+    raster_stages = ["mark_visible", "preprocess", "scan", "duplicate_with_keys", "sort", "identify_ranges", "render_forward",
+                     "zero_partials", "render_backward", "backward_preprocess"]
     # HBM bytes per launch: rocprofv3 --pmc passes of THIS command (tools/pmc_traffic.sh runs bench.py under the profiler and
     # writes profiles/traffic_latest.json; counters cannot be read from inside the process that is being timed)
     traffic_all, traffic_src = {}, None

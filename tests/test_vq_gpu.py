@@ -226,3 +226,38 @@ def test_weighted_distance_nan_rows_fall_back_to_codeword_zero(hip):
     ok = torch.ones(300, dtype=torch.bool); ok[7] = ok[200] = False
     d2, i2 = hip.weightedDistance(x[ok].cuda(), cb.cuda())
     assert torch.equal(i[ok.cuda()], i2) and torch.equal(d[ok.cuda()], d2)
+
+
+_NCCL_CHILD = r"""
+import os, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29591")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import c3dgs_amd
+g = torch.Generator().manual_seed(3)
+N, D, K, steps, chunk = 60_000, 48, 256, 6, 2 ** 13
+f = (torch.randn(N, D, generator=g) * 0.1).float().cuda()
+imp = torch.rand(N, generator=g).pow(4).float().cuda()
+init = torch.rand(K, D, generator=g)
+torch.manual_seed(5)
+cb_g, idx_g, err_g = c3dgs_amd.vq_features(f, imp, K, chunk, steps, init_rand=init, silent=True, group=True, return_errors=True)
+torch.manual_seed(5)
+cb_s, idx_s, err_s = c3dgs_amd.vq_features(f, imp, K, chunk, steps, init_rand=init, silent=True, return_errors=True)
+assert torch.allclose(cb_g, cb_s, rtol=1e-4, atol=1e-6) and (idx_g == idx_s).float().mean() >= 0.999
+assert all(abs(a - b) <= 1e-6 * abs(b) + 1e-12 for a, b in zip(err_g, err_s)), (err_g, err_s)
+dist.destroy_process_group()
+print("NCCL_OK")
+"""
+
+
+def test_sharded_path_runs_on_the_nccl_backend():
+    """The sharded Lloyd loop's collectives (generator-state broadcast, in-place all-reduce of S, all-reduce of the error sums,
+    all_gather of the final assignment) on the `nccl` (= RCCL) backend with device tensors -- a one-rank group is what a
+    one-GPU box can host; the multi-rank logic is covered over gloo (tests/test_dist_cpu.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _NCCL_CHILD], cwd=root, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "NCCL_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
