@@ -257,21 +257,30 @@ void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* poi
 
 // ---------------------------------------------------------------- backward
 //
-// Per (wave, Gaussian) the 9 gradient terms must be summed over the wave's 64 pixels. A plain butterfly costs
-// 6 cross-lane adds per value (54 per Gaussian). Instead GROUP_G = 7 Gaussians (63 values + 1 pad) are reduced
-// TOGETHER by a transposing network: at every step a lane pair exchanges halves, each lane keeps half of the
-// values it held and adds its partner's copy of that half, so the live values per lane halve while the lanes
-// summed per value double:
-//    64 -> 32 values  row_ror:8           (lane bit 3 picks the half)        v_add_f32_dpp
-//    32 -> 16         row_half_mirror     (lane bit 2)
-//    16 ->  8         quad_perm [1,0,3,2] (lane bit 0)
-//     8 ->  4         quad_perm [2,3,0,1] (lane bit 1)      -> each lane: 4 values summed over its 16-lane row
-//     4 ->  2         v_permlane16_swap   (lane bit 4)
-//     2 ->  1         v_permlane32_swap   (lane bit 5)      -> lane l holds the wave total of value idx(l)
-// = 60 DPP adds + 120 selects + 3 swaps per 7 Gaussians (~26 per Gaussian instead of ~95), and the 63 results
-// sit in 63 different lanes, so ONE ds_write_b32 stores them all.
+// Per (wave, Gaussian) nine gradient terms must be summed over the wave's 64 pixels: three colour terms and six moments
+// of w = G * dL/dalpha. A plain butterfly costs 6 cross-lane adds per value (54 per Gaussian). Two ideas cut that to ~15:
+//
+// (1) SEPARABLE MOMENTS. Within a pixel row dy = mean.y - pixel.y is the same for the row's 8 lanes, so a lane only forms
+//     w, w dx, w dx^2 (dx = mean.x - pixel.x, which the alpha evaluation already has) -- not w dy, w dx dy, w dy^2 --, the
+//     sums over the row's 8 columns are taken on SIX values per Gaussian, and each row sum is expanded to the nine terms
+//     with three multiplies (S_y = dy R0, S_xy = dy R1, S_yy = dy^2 R0) before the sums over the 8 rows. Same quantities as
+//     the per-pixel products (dy is merely factored out of the row sums), three multiplies fewer per pair, and a third of
+//     the values leave the first three reduction levels.
+// (2) TRANSPOSING NETWORK. GROUP_G = 8 Gaussians are reduced TOGETHER: at every level a lane pair exchanges halves, each lane
+//     keeps half of the values it held and adds its partner's copy of that half, so the live values per lane halve while the
+//     lanes summed per value double:
+//        columns (lane bits 2, 0, 1):  48 -> 24  row_half_mirror (bank-masked v_add_f32_dpp, no selects)
+//                                      24 -> 12  quad_perm [1,0,3,2]
+//                                      12 ->  6  quad_perm [2,3,0,1]     -> lane holds the 6 row sums of Gaussian beta(lane)
+//        expand 6 -> 9 (three multiplies by dy, dy, dy^2 of Gaussian beta(lane) on this pixel row)
+//        rows (lane bits 3, 4, 5):      8 ->  4  row_ror:8 (bank-masked)   + the ninth value by a plain add at each level
+//                                       4 ->  2  v_permlane16_swap
+//                                       2 ->  1  v_permlane32_swap        -> lane holds term m(lane) of Gaussian beta(lane)
+//     ~124 vector instructions per 8 Gaussians (the 64-value network of round 1: ~140 per 7), and the 64 + 8 results sit in
+//     different lanes, so two ds_add_f32 instructions deliver them.
 constexpr int NPART = PARTIAL_FLOATS; // 9
-constexpr int GROUP_G = 7;
+constexpr int GROUP_G = 8;
+constexpr int NCOL = 6;               // values per Gaussian that go through the column levels
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_take(float v)
@@ -288,13 +297,6 @@ __device__ __forceinline__ void transpose_reduce_step(float* v, bool hi)
         const float send = hi ? v[k] : v[k + N / 2];
         v[k] = keep + dpp_take<CTRL>(send);
     }
-}
-
-// value index that ends up in lane l after the network (see the table above)
-__device__ __forceinline__ int reduced_index_of_lane(int l)
-{
-    return (((l >> 3) & 1) << 5) | (((l >> 2) & 1) << 4) | ((l & 1) << 3) | (((l >> 1) & 1) << 2) | (((l >> 4) & 1) << 1) |
-           ((l >> 5) & 1);
 }
 
 // Steps 1 and 2 pair lanes that sit in different DPP banks (4-lane groups), so "which half do I keep" is
@@ -316,24 +318,37 @@ __device__ __forceinline__ int reduced_index_of_lane(int l)
                  : "v"(a[base]), "v"(a[base + 1]), "v"(a[base + 2]), "v"(a[base + 3]), "v"(b[base + half]),               \
                    "v"(b[base + half + 1]), "v"(b[base + half + 2]), "v"(b[base + half + 3]))
 
-__device__ __forceinline__ float transpose_reduce_64(float* v, int lane)
+// column levels: v[48] = 8 Gaussians x 6 values -> u[0..5] = the sums over the lane's 8-pixel row of the 6 values of
+// Gaussian slot beta(lane) = 4 * bit2 + 2 * bit0 + bit1
+__device__ __forceinline__ void reduce_columns_48(const float* v, float* u, int lane)
 {
-    float w[32], u[16];
-    // 64 -> 32: row_ror:8 (lane i <-> i^8); lanes 0-7 = banks 0,1 keep v[k], lanes 8-15 = banks 2,3 keep v[k+32]
+    // 48 -> 24: row_half_mirror (i <-> 7 - i); lanes with bit 2 clear = banks 0,2 keep v[k], banks 1,3 keep v[k+24]
 #pragma unroll
-    for (int q = 0; q < 32; q += 4) C3DGS_TR4("row_ror:8", "0x3", "0xc", w, v, v, q, 32);
-    // 32 -> 16: row_half_mirror (i <-> i^7); lanes with bit 2 clear = banks 0,2 keep w[k], banks 1,3 keep w[k+16]
-#pragma unroll
-    for (int q = 0; q < 16; q += 4) C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, w, w, q, 16);
-    transpose_reduce_step<16, 0xB1>(u, (lane & 1) != 0);   // quad_perm [1,0,3,2]: partners share a bank -> selects
-    transpose_reduce_step<8, 0x4E>(u, (lane & 2) != 0);    // quad_perm [2,3,0,1]
-    // rows: u[0..3] indexed (b1,b0); odd rows keep b1 = 1
-    auto s0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[0]), __float_as_uint(u[2]), false, false);
-    auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[1]), __float_as_uint(u[3]), false, false);
+    for (int q = 0; q < 24; q += 4) C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, q, 24);
+    transpose_reduce_step<24, 0xB1>(u, (lane & 1) != 0);   // quad_perm [1,0,3,2]: partners share a bank -> selects
+    transpose_reduce_step<12, 0x4E>(u, (lane & 2) != 0);   // quad_perm [2,3,0,1]
+}
+
+// row levels: n[0..8] -> total = sum over the lane's column (8 rows) of n[m(lane)], m = 4 * bit3 + 2 * bit4 + bit5, and
+// ninth = the same sum of n[8] (in every lane of the column)
+__device__ __forceinline__ void reduce_rows_9(const float* n, float& total, float& ninth)
+{
+    float o[4];
+    // 8 -> 4: row_ror:8 (lane i <-> i^8); lanes 0-7 = banks 0,1 keep n[k], lanes 8-15 = banks 2,3 keep n[k+4]
+    C3DGS_TR4("row_ror:8", "0x3", "0xc", o, n, n, 0, 4);
+    float t8;
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=&v"(t8) : "v"(n[8]));
+    // v_permlane16_swap: the odd 16-lane rows of the first operand trade places with the even rows of the second
+    auto s0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[0]), __float_as_uint(o[2]), false, false);
+    auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[1]), __float_as_uint(o[3]), false, false);
+    auto s8 = __builtin_amdgcn_permlane16_swap(__float_as_uint(t8), __float_as_uint(t8), false, false);
     const float w0 = __uint_as_float(s0[0]) + __uint_as_float(s0[1]);
     const float w1 = __uint_as_float(s1[0]) + __uint_as_float(s1[1]);
+    const float w8 = __uint_as_float(s8[0]) + __uint_as_float(s8[1]);
     auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w0), __float_as_uint(w1), false, false);
-    return __uint_as_float(s2[0]) + __uint_as_float(s2[1]);
+    auto s9 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w8), __float_as_uint(w8), false, false);
+    total = __uint_as_float(s2[0]) + __uint_as_float(s2[1]);
+    ninth = __uint_as_float(s9[0]) + __uint_as_float(s9[1]);
 }
 
 #ifndef C3DGS_BWD_WPE
@@ -358,7 +373,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     __shared__ uint32_t s_slot[BATCH];
     // per wave: its candidates of HALF a batch (128 entries) at a time, 7 per 32-byte row (one row = one reduction group);
     // half batches keep the kernel's LDS at 31 KB = five workgroups per CU
-    __shared__ uint32_t s_list[4][(BATCH / 2 / GROUP_G + 2) * 8];
+    __shared__ uint32_t s_list[4][BATCH / 2 + GROUP_G];
     __shared__ unsigned long long s_mask[4][4];      // [quadrant][staging wave]
     __shared__ float s_part[2][BATCH][NPART];         // one plane per wave PAIR (see the flush below)
     constexpr uint32_t REC_BYTES = 32;
@@ -396,9 +411,9 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, o));
     wave_last = __builtin_amdgcn_readfirstlane(wave_last);      // tell the compiler it is wave-uniform (scalar loop control)
-    // where this lane's reduced value goes: value index = g*9 + c
-    const int my_idx = reduced_index_of_lane(lane);
-    const int my_g = my_idx / NPART, my_c = my_idx - my_g * NPART;
+    // where this lane's reduced values belong: Gaussian slot beta of the group, term my_m of the nine (see the network above)
+    const int beta = ((lane >> 2) & 1) * 4 + (lane & 1) * 2 + ((lane >> 1) & 1);
+    const int my_m = ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
 
     for (int r = 0; r < rounds; r++) {
         __syncthreads();                                         // previous flush has read s_part / s_slot
@@ -444,27 +459,20 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                 // entries with pos >= wave_last (j <= pos0 - wave_last) are behind every pixel of this wave
                 const int jmin = pos0 - wave_last + 1 - c * 64;
                 if (jmin >= 64) m = 0; else if (jmin > 0) m &= ~0ull << jmin;
-                if ((m >> lane) & 1ull) {
-                    const int p = nw + (int)__popcll(m & lt), row = p / GROUP_G;
-                    s_list[wave][row * 8 + (p - row * GROUP_G)] = (uint32_t)(c * 64 + lane) * REC_BYTES;
-                }
+                if ((m >> lane) & 1ull) s_list[wave][nw + (int)__popcll(m & lt)] = (uint32_t)(c * 64 + lane) * REC_BYTES;
                 nw += (int)__popcll(m);
             }
-            if (lane < GROUP_G) {
-                const int p = nw + lane, row = p / GROUP_G;
-                s_list[wave][row * 8 + (p - row * GROUP_G)] = (uint32_t)BATCH * REC_BYTES;
-            }
+            if (lane < GROUP_G) s_list[wave][nw + lane] = (uint32_t)BATCH * REC_BYTES;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         for (int k = 0; k < nw; k += GROUP_G) {
-            const uint32_t* lrow = &s_list[wave][(k / GROUP_G) * 8];
+            const uint32_t* lrow = &s_list[wave][k];
             const uint4 row0 = *reinterpret_cast<const uint4*>(lrow);
             const uint4 row1 = *reinterpret_cast<const uint4*>(lrow + 4);
-            const uint32_t e[GROUP_G] = { row0.x, row0.y, row0.z, row0.w, row1.x, row1.y, row1.z };
-            float v[64];
-            v[63] = 0.f;                                         // pad: 7 x 9 = 63 values
+            const uint32_t e[GROUP_G] = { row0.x, row0.y, row0.z, row0.w, row1.x, row1.y, row1.z, row1.w };
+            float v[GROUP_G * NCOL];
 #pragma unroll
             for (int g = 0; g < GROUP_G; g++) {
                 const float4 a = *reinterpret_cast<const float4*>(rec_base + e[g]);
@@ -474,38 +482,41 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                 bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
                 hit = hit && ((int)e[g] > thr);                  // backward.cu:486-488
                 // branch-free: a pixel that does not blend this Gaussian runs the same instructions with
-                // alpha = G = 0, which leaves T and Sd untouched and makes all nine terms exactly 0
+                // alpha = G = 0, which leaves T and Sd untouched and makes all six terms exactly 0
                 const float a_eff = hit ? alpha : 0.f, G_eff = hit ? G : 0.f;
                 // 1/(1-alpha) once, as a hardware reciprocal (1 ulp; 1-alpha is in [0.01, 1]; rcp(1) == 1)
                 const float rinv = __builtin_amdgcn_rcpf(1.f - a_eff);
                 Tr = Tr * rinv;                                  // transmittance in front of this Gaussian
                 const float dchannel_dcolor = a_eff * Tr;
                 const float cd = fmaf(cblue, dpx2, fmaf(b.w, dpx1, b.z * dpx0));
-                v[g * NPART + 0] = dchannel_dcolor * dpx0;
-                v[g * NPART + 1] = dchannel_dcolor * dpx1;
-                v[g * NPART + 2] = dchannel_dcolor * dpx2;
+                v[g * NCOL + 0] = dchannel_dcolor * dpx0;
+                v[g * NCOL + 1] = dchannel_dcolor * dpx1;
+                v[g * NCOL + 2] = dchannel_dcolor * dpx2;
                 const float dL_dalpha = fmaf(Tr, cd, -(rinv * Sd));
                 Sd = fmaf(dchannel_dcolor, cd, Sd);
-                // raw moments of w = G*dL_dalpha about the Gaussian's mean; the per-Gaussian linear maps to
-                // dL_dmean2D / dL_dconic / dL_dopacity (backward.cu:538-554) are applied ONCE per Gaussian,
-                // after the sum over pixels and tiles, in backward_preprocess.hip
-                const float w = G_eff * dL_dalpha;
-                const float wx = w * dx, wy = w * dy;
-                v[g * NPART + 3] = w;
-                v[g * NPART + 4] = wx;
-                v[g * NPART + 5] = wy;
-                v[g * NPART + 6] = wx * dx;
-                v[g * NPART + 7] = wx * dy;
-                v[g * NPART + 8] = wy * dy;
+                // w = G * dL/dalpha and its first two x-moments about the mean; the y-moments follow from the row sums
+                const float w = G_eff * dL_dalpha, wx = w * dx;
+                v[g * NCOL + 3] = w;
+                v[g * NCOL + 4] = wx;
+                v[g * NCOL + 5] = wx * dx;
             }
-            const float total = transpose_reduce_64(v, lane);
-            // batch entry of the group slot this lane's reduced value belongs to (slot 7 of a row is padding: my_idx 63)
-            const uint32_t my_off = lrow[my_g];
+            float u[GROUP_G * NCOL / 2];
+            reduce_columns_48(v, u, lane);
+            // batch entry of this lane's Gaussian slot (the list's padding entries are the sentinel, BATCH) and this pixel
+            // row's dy to that Gaussian: the same subtraction gaussian_alpha made for it
+            const uint32_t my_off = lrow[beta];
             const int myj = (int)(my_off >> 5);                  // offset / 32
+            const float dyb = *reinterpret_cast<const float*>(rec_base + my_off + 4) - pyf;
+            // row sums {c0, c1, c2, S0, Sx, Sxx} of Gaussian slot beta -> the nine terms {.., Sy, Sxy | Syy}
+            const float nine[NPART] = { u[0], u[1], u[2], u[3], u[4], u[5], dyb * u[3], dyb * u[4], (dyb * dyb) * u[3] };
+            float total, ninth;
+            reduce_rows_9(nine, total, ninth);
             // LDS float add into the plane this wave shares with ONE other wave: every (entry, term) receives at most
             // one add per wave, and a + b == b + a, so the result does not depend on which wave arrives first
-            if (my_idx < GROUP_G * NPART && myj < BATCH)
-                __hip_atomic_fetch_add(&s_part[wave >> 1][myj][my_c], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (myj < BATCH) {
+                __hip_atomic_fetch_add(&s_part[wave >> 1][myj][my_m], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane < 8) __hip_atomic_fetch_add(&s_part[wave >> 1][myj][8], ninth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the list is rebuilt for the second half
         __builtin_amdgcn_wave_barrier();
@@ -514,9 +525,13 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
         if (tid < cnt) {
             const uint32_t slot = s_slot[tid];
             float* dst = partials + (size_t)slot * NPART;
+            float t[NPART];
 #pragma unroll
-            for (int q = 0; q < NPART; q++)
-                dst[q] = s_part[0][tid][q] + s_part[1][tid][q];      // (w0 + w1) + (w2 + w3): fixed order, reproducible
+            for (int q = 0; q < NPART; q++) t[q] = s_part[0][tid][q] + s_part[1][tid][q];   // (w0 + w1) + (w2 + w3): fixed order
+            // network order {c0, c1, c2, S0, Sx, Sxx, Sy, Sxy, Syy} -> what backward_preprocess.hip expects
+            dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2];
+            dst[3] = t[3]; dst[4] = t[4]; dst[5] = t[6];
+            dst[6] = t[5]; dst[7] = t[7]; dst[8] = t[8];
             touched[slot] = 1;
         }
     }
