@@ -448,9 +448,11 @@ static void launch_wd_mfma(int64_t N, int C, const float* coefs, const int64_t* 
                            int64_t* out_idx, int* flag_list, int flag_cap, hipStream_t s)
 {
     const unsigned g1 = (unsigned)((N + 4 * MF_PTS - 1) / (4 * MF_PTS)), g2 = (unsigned)((N + 63) / 64);
-    // fewer than two 4-wave workgroups per CU (256 CUs): let the 4 waves share 64 points and split the codebook instead
+    // fewer than one 4-wave workgroup per CU (256 CUs): let the 4 waves share 64 points and split the codebook instead
+    // (measured, K = 4096 x 48: N = 32,768: 267 -> 158 us; N = 65,536: 271 vs 283 us, so the plain kernel from there on;
+    // profiles/r02a_vq_slices.txt)
     static const int split_env = []() { const char* e = getenv("C3DGS_VQ_SPLIT"); return e ? atoi(e) : -1; }();   // A/B switch for tests
-    const bool split = split_env >= 0 ? split_env != 0 : g1 < 512;
+    const bool split = split_env >= 0 ? split_env != 0 : g1 < 256;
     const bool listed = flag_list && flag_cap > 0 && N < ((int64_t)1 << 31);
     if (listed) (void)hipMemsetAsync(flag_list, 0, sizeof(int), s);
     if (split) wd_mfma_kernel<K, true><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, listed ? flag_list : nullptr, listed ? flag_cap : 0);
