@@ -1,6 +1,7 @@
 """CPU: host-side logic of the drop-in Python surface (no kernels): camera set-up, argument checks, the factored
 camera-pose Jacobian against the reference's closed form (golden vector), module aliasing, and the hard failure on
 CPU tensors (the package has no CPU path)."""
+import math
 import os
 import sys
 
@@ -62,6 +63,25 @@ def test_camera_pose_jacobian_matches_reference_closed_form():
                                       torch.from_numpy(d["extrinsic_vector"]), torch.from_numpy(d["du"]),
                                       torch.from_numpy(d["dv"]))
     np.testing.assert_allclose(got.numpy(), d["grad_mat"], rtol=2e-4, atol=1e-4)
+
+
+def test_reference_pose_closed_form_is_not_the_projection(orc):
+    """VERDICT r1 asked to pin the kernels' NDC projection with the polynomials numU / den of the reference's camera-pose
+    closed form (__init__.py:674-788). They cannot: numU / den is not p_hom.x / p_hom.w of the projection the reference's own
+    matrices (quat_to_mat @ getProjectionMatrix, golden camera.npz) define -- documented here so nobody relies on it."""
+    d = np.load(os.path.join(G, "camgrad.npz"), allow_pickle=False)
+    m, intr, ev = d["means3D"].astype(np.float64), d["intrinsic"], d["extrinsic_vector"]
+    X, Y, Z = m[:, 0], m[:, 1], m[:, 2]
+    qx, qy, qz, qw, tx, ty, tz = [float(v) for v in ev]
+    Xs, Ys = X / math.tan(float(intr[0, 0]) / 2), Y / math.tan(float(intr[1, 1]) / 2)
+    numU = (Xs * (2 * qx ** 2 - 4 * qx * qy - 2 * qz ** 2 + 1) + Ys * (-2 * qw * qz + 2 * qx * qy)
+            + Z * (2.000200020002 * (qw * qy + qx * qz) + tx) - 0.02000200020002 * (qw * qy + qx * qz))
+    den = (Xs * (-2 * qw * qy + 2 * qx * qz) + Ys * (2 * qw * qx + 2 * qy * qz)
+           + Z * (-4.000400040004 * qx * qy + tz + 1.000100010001) + 0.04000400040004 * qx * qy - 0.01000100010001)
+    cam = orc.camera(intr, ev)
+    hom = np.concatenate([m, np.ones((len(m), 1))], 1) @ cam["projmatrix"].astype(np.float64).reshape(4, 4)
+    ndc_x = hom[:, 0] / (hom[:, 3] + 1e-7)
+    assert np.abs(numU / den - ndc_x).max() > 0.05
 
 
 def test_argument_checks_and_no_cpu_path():
