@@ -125,3 +125,27 @@ def test_vq_final_assignment_5p4M(hip, orc):
         exact = ((xd[lo:hi] - cbd[i[lo:hi]]) ** 2).sum(-1)
         torch.testing.assert_close(d[lo:hi], exact, rtol=1e-5, atol=1e-7)
     _exactness_properties(hip, xd, cbd, d, i, g)
+
+
+def test_config5_composed_pipeline_6M(hip, tmp_path):
+    """BASELINE.json configs[4] at full scene size through the public API (tools/run_config5.py: 6M Gaussians, 32 cameras at
+    1080p, sensitivity pass -> prune + VQ with the reference's settings (colour 100 steps of 2^18, covariance 800 steps of
+    2^20, 2^12 codebooks) -> QAT fine-tuning -> Morton-sorted npz). Only the number of fine-tuning iterations is cut (60 of
+    5000: a fixed-cost loop of identical steps). Checked: it runs, the payload is a real compression, and the compressed
+    model still renders the uncompressed model's images (PSNR)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "config5.json"
+    r = subprocess.run([sys.executable, "tools/run_config5.py", "--finetune", "60", "--out", str(out)], cwd=root,
+                       capture_output=True, text=True, timeout=1100)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.load(open(out))
+    assert res["gaussians"] == 6_000_000 and res["cameras"] == 32 and res["resolution"] == [1920, 1080]
+    assert res["compression_ratio"] > 50 and 0 < res["payload_MiB"] < res["uncompressed_fp32_MiB"]
+    assert res["psnr_vs_uncompressed_after_vq_dB"] >= 40.0 and res["psnr_vs_uncompressed_after_finetune_dB"] >= 40.0
+    t = res["timings_s"]
+    assert t["finetune_iterations"] == 60 and 0 < t["finetune_ms_per_iteration"] < 50 and t["clustering"] < 60 and t["sensitivity_calculation"] < 60
+    print("config5", {k: round(v, 3) if isinstance(v, float) else v for k, v in res.items() if k != "timings_s"}, t)
