@@ -335,10 +335,14 @@ def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size:
     if world > 1 and shard_final:
         lo, hi = (rank * N) // world, ((rank + 1) * N) // world
         _, local = vq_model.ops.assign(feats[lo:hi], vq_model.codebook.data)
+        # ranges differ by at most one point; RCCL's all-gather wants equal counts, so every rank sends ceil(N / world) slots
         sizes = [((r + 1) * N) // world - (r * N) // world for r in range(world)]
-        parts = [torch.empty(sz, dtype=torch.int64, device=dev) for sz in sizes]
-        dist.all_gather(parts, local, group=pg)
-        vq_indices = torch.cat(parts, 0)
+        width = max(sizes)
+        send = torch.zeros(width, dtype=torch.int64, device=dev)
+        send[:hi - lo] = local
+        gathered = torch.empty(world * width, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gathered, send, group=pg)
+        vq_indices = torch.cat([gathered[r * width:r * width + sz] for r, sz in enumerate(sizes)], 0)
     else:
         _, vq_indices = vq_model(feats)
     if vq_indices.is_cuda:

@@ -22,7 +22,7 @@ def _free_port():
 
 def _problem(scale_normalize):
     g = torch.Generator().manual_seed(0)
-    N, D, K, steps, chunk = 3000, (6 if scale_normalize else 12), 32, 6, 501     # 501: ragged split across 2 ranks
+    N, D, K, steps, chunk = 3001, (6 if scale_normalize else 12), 32, 6, 501     # 3001 points, 501 per batch: ragged splits across 2 ranks
     f = (torch.randn(N, D, generator=g) * 0.1).float()
     if scale_normalize:
         f[:, [0, 3, 5]] = f[:, [0, 3, 5]].abs() + 0.2
@@ -46,7 +46,7 @@ def _worker(rank, world, port, scale_normalize, out_dir):
     # agree bit for bit although they were seeded differently; and the collectives are counted: per Lloyd step exactly one
     # all-reduce (of S) and no broadcast
     torch.manual_seed(100 + rank)
-    counts = {"all_reduce": 0, "broadcast": 0, "all_gather": 0}
+    counts = {"all_reduce": 0, "broadcast": 0, "all_gather_into_tensor": 0}
     orig = {k: getattr(dist, k) for k in counts}
 
     def counting(name):
@@ -63,7 +63,7 @@ def _worker(rank, world, port, scale_normalize, out_dir):
             setattr(dist, k, orig[k])
     after = torch.randint(0, 1 << 30, (4,))                    # all ranks were left at the same generator state
     np.savez(os.path.join(out_dir, f"rng_rank{rank}.npz"), cb=cb2.numpy(), idx=idx2.numpy(), after=after.numpy(),
-             counts=np.array([counts["all_reduce"], counts["broadcast"], counts["all_gather"]]))
+             counts=np.array([counts["all_reduce"], counts["broadcast"], counts["all_gather_into_tensor"]]))
     dist.destroy_process_group()
 
 
@@ -90,7 +90,7 @@ def test_sharded_vq_matches_single_rank(tmp_path, scale_normalize):
     np.testing.assert_allclose(r0["cb"], cb.numpy(), rtol=1e-5, atol=1e-7)
     assert (r0["idx"] == idx.numpy()).mean() >= 0.999
     np.testing.assert_allclose(r0["errs"], np.array(errs), rtol=1e-6)
-    assert r0["idx"].shape == (3000,)
+    assert r0["idx"].shape == (3001,)
 
 
 def test_oracle_ops_equal_oracle_update(orc):
