@@ -125,14 +125,16 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     if (!radii) return fail(C3DGS_E_INVALID, "radii is required");
 
     c3dgs_geom_layout GL; geom_layout(P, &GL);
-    void* geom_base = geom_resize(geom_user, GL.total_bytes);
+    void* geom_base = geom_resize(geom_user, GL.total_bytes + geom_gtab_bytes(p));
     if (!geom_base) return fail(C3DGS_E_ALLOC, "geometry buffer allocation failed");
     const GeomPtrs g = geom_ptrs(geom_base, P);
 
     // K2 / K2i, with the id-order scan of tiles_touched folded in (per-workgroup offsets + block_base[])
     uint32_t* sort_err = onesweep_error_word();
     if (!sort_err) return fail(C3DGS_E_HIP, "cannot resolve the sort error word");
-    { StageTimer t_(ST_PREPROCESS, s); launch_preprocess(p, g, radii, img.ranges, sort_err, s); }
+    { StageTimer t_(ST_PREPROCESS, s);
+      if (geom_gtab_bytes(p)) launch_pack_codebook(p, g.gtab, s);
+      launch_preprocess(p, g, radii, img.ranges, sort_err, s); }
     C3DGS_STAGE("preprocess", p.debug, s);
     // The one device->host read of the forward (K4, num_rendered) is issued as EARLY as its value exists: R is the last
     // entry of block_base[]. The copy lands in pinned memory behind an event while the depth sort and the depth-order

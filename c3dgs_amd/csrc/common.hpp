@@ -76,6 +76,12 @@ inline void geom_layout(int P, c3dgs_geom_layout* L)
     L->total_bytes = o;
 }
 
+// The indexed variant gathers a Gaussian's rotation (16 B) and scale (12 B) from two codebooks by the same random index:
+// four gather instructions over up to 256 different cache lines per wave. Packed once per forward into ONE 32-byte row per
+// codebook entry {rotation | scale, 0} (stored behind the P-sized part of the geometry buffer, so the backward finds it too),
+// the same data arrives with two 16-byte loads from one line per Gaussian (preprocess 0.268 -> see DESIGN.md).
+inline size_t geom_gtab_bytes(const c3dgs_raster_params& p) { return (p.g_indices && p.scales) ? align_up((size_t)(p.GS > 0 ? p.GS : 1) * 32) : 0; }
+
 inline void binning_layout(int R, int W, int H, c3dgs_binning_layout* L)
 {
     size_t o = 0, r = (size_t)(R > 0 ? R : 1);
@@ -104,6 +110,7 @@ struct GeomPtrs {
     float4* splat; uint32_t* depth_keys; uint32_t* depth_keys_sorted;
     uint32_t* depth_order; uint2* sorted_offsets; uint32_t* inst_offset; uint16_t* rects;
     uint8_t* clamped; uint32_t* block_base; uint32_t* depth_base; void* scan_temp; size_t scan_temp_bytes;
+    float4* gtab;     // indexed variant: the scale / rotation codebooks packed as one 32-byte row per entry (behind the P-sized part)
 };
 struct BinPtrs {
     uint16_t* keys_unsorted; uint32_t* values_unsorted; uint16_t* keys_sorted; uint32_t* point_list;
@@ -118,7 +125,7 @@ inline GeomPtrs geom_ptrs(void* base, int P)
     return { (float4*)(b + L.splat), (uint32_t*)(b + L.depth_keys), (uint32_t*)(b + L.depth_keys_sorted), (uint32_t*)(b + L.depth_order),
              (uint2*)(b + L.sorted_offsets), (uint32_t*)(b + L.inst_offset), (uint16_t*)(b + L.rects),
              (uint8_t*)(b + L.clamped), (uint32_t*)(b + L.block_base), (uint32_t*)(b + L.depth_base), (void*)(b + L.scan_temp),
-             L.scan_temp_bytes };
+             L.scan_temp_bytes, (float4*)(b + L.total_bytes) };
 }
 inline BinPtrs bin_ptrs(void* base, int R, int W, int H)
 {
@@ -137,6 +144,7 @@ inline ImgPtrs img_ptrs(void* base, int W, int H)
 // preprocess.hip
 void launch_camera_from_pose(const float* pose, float inv_tan_x, float inv_tan_y, float* view, float* proj, float* campos, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+void launch_pack_codebook(const c3dgs_raster_params& p, float4* gtab, hipStream_t s);
 void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, const uint32_t* sort_err, hipStream_t s);
 void launch_depth_order_scan(int P, const GeomPtrs& g, hipStream_t s);   // block totals of tiles_sorted -> depth_base[]
 void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, hipStream_t s);

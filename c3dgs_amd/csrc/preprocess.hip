@@ -29,6 +29,21 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
     present[i] = !(pv.z <= 0.01f) ? 1 : 0;
 }
 
+__global__ void __launch_bounds__(256)
+pack_codebook_kernel(int GS, const float* __restrict__ scales, const float* __restrict__ rotations, float4* __restrict__ gtab)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= GS) return;
+    gtab[2 * (size_t)g] = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)g);
+    gtab[2 * (size_t)g + 1] = make_float4(scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2], 0.f);
+}
+
+void launch_pack_codebook(const c3dgs_raster_params& p, float4* gtab, hipStream_t s)
+{
+    if (p.GS <= 0) return;
+    pack_codebook_kernel<<<(p.GS + 255) / 256, 256, 0, s>>>(p.GS, p.scales, p.rotations, gtab);
+}
+
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s)
 {
     if (P <= 0) return;
@@ -121,6 +136,7 @@ struct PreArgs {
     uint32_t* depth_keys;
     uint32_t* inst_offset; uint32_t* block_total;   // two-level id-order scan
     uint2* ranges; int T;                            // tile ranges, cleared here for identify_ranges (K7)
+    const float4* gtab;                              // packed scale / rotation codebook (indexed variant)
 };
 
 // The id-order scan of tiles_touched (where a Gaussian's backward partial-sum slots live; its total is num_rendered) is
@@ -159,9 +175,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
             for (int q = 0; q < 6; q++) cov3D[q] = a.cov3D_precomp[6 * (size_t)i + q];
         } else if (a.g_indices) {                                  // forward_indexed.cu:223
             const size_t g = (size_t)a.g_indices[i];
-            const float4 rot = *reinterpret_cast<const float4*>(a.rotations + 4 * g);
-            cov3d_from_scale_rot(a.scales[3 * g], a.scales[3 * g + 1], a.scales[3 * g + 2],
-                                 a.scale_factors[i] * a.scale_modifier, rot, cov3D);
+            const float4 rot = a.gtab[2 * g], sc = a.gtab[2 * g + 1];     // one 32-byte row: {rotation | scale, 0}
+            cov3d_from_scale_rot(sc.x, sc.y, sc.z, a.scale_factors[i] * a.scale_modifier, rot, cov3D);
         } else {                                                   // forward.cu:220
             const float4 rot = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)i);
             cov3d_from_scale_rot(a.scales[3 * (size_t)i], a.scales[3 * (size_t)i + 1], a.scales[3 * (size_t)i + 2],
@@ -303,6 +318,7 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
     a.inst_offset = g.inst_offset;
     a.block_total = g.block_base;     // totals in, exclusive bases out (scan_blocks_kernel)
     a.ranges = ranges; a.T = a.gx * a.gy;
+    a.gtab = g.gtab;
     const dim3 grid((p.P + 255) / 256), block(256);
     const int deg = p.colors_precomp ? 0 : p.D;
     switch (deg) {
