@@ -5,7 +5,7 @@
 // look-back instead of a global scan), written for this workload:
 //   * ONE memset per sort (digit histograms + look-back words + tickets are one contiguous block) instead of the two
 //     5-microsecond fill launches rocPRIM issues in front of every digit pass (14 per forward);
-//   * 8192-item tiles (1024 threads x 8 for the u16 tile keys, 512 x 16 for the u32 depth keys): measured 0.228 ms against 0.267 ms for the 16.4 M (u16, u32) tile-key pairs;
+//   * 8192-item tiles of 1024 threads for the u16 tile keys, 12288-item tiles of 512 threads for the u32 depth keys: measured 0.228 ms against 0.267 ms for the 16.4 M (u16, u32) tile-key pairs;
 //   * digit widths chosen per sort (13 tile bits = 7 + 6), keys of the native width.
 // Structure of one digit pass (os_pass_kernel), per 8192-item tile:
 //   ticket      blocks take their tile index from an atomic counter, so every predecessor of a block is already running
@@ -28,14 +28,20 @@ constexpr int OS_RADIX = 256;
 // tile shape per key width (measured): u16 keys 8192-item tiles, 1024 threads x 8 items; u32 keys C3DGS_OS_TILE32 items with
 // C3DGS_OS_BLOCK32 threads (82 KB of LDS would allow only one 1024-thread workgroup per CU)
 #ifndef C3DGS_OS_TILE32
-#define C3DGS_OS_TILE32 8192
+#define C3DGS_OS_TILE32 12288   // round 2 (tools/ablate_sort2.sh, 3M keys): 8192 x 512 0.205 ms, 12288 x 512 0.191, 16384 x 512 0.209, 16384 x 1024 0.194
 #endif
 #ifndef C3DGS_OS_BLOCK32
 #define C3DGS_OS_BLOCK32 512
 #endif
+#ifndef C3DGS_OS_TILE16
+#define C3DGS_OS_TILE16 8192    // 16.4 M (u16, u32) pairs: 8192 x 1024 0.215 ms, 12288 x 1024 0.243, 16384 x 1024 0.225
+#endif
+#ifndef C3DGS_OS_BLOCK16
+#define C3DGS_OS_BLOCK16 1024
+#endif
 template <class K> struct OsShape {
-    static constexpr int TILE = sizeof(K) == 2 ? 8192 : C3DGS_OS_TILE32;
-    static constexpr int BLOCK = sizeof(K) == 2 ? 1024 : C3DGS_OS_BLOCK32;
+    static constexpr int TILE = sizeof(K) == 2 ? C3DGS_OS_TILE16 : C3DGS_OS_TILE32;
+    static constexpr int BLOCK = sizeof(K) == 2 ? C3DGS_OS_BLOCK16 : C3DGS_OS_BLOCK32;
     static constexpr int IPT = TILE / BLOCK;
 };
 constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_PRE = 2u << 30, OS_CNT_MASK = (1u << 30) - 1;
