@@ -230,7 +230,7 @@ def test_weighted_distance_nan_rows_fall_back_to_codeword_zero(hip):
 
 _NCCL_CHILD = r"""
 import os, torch, torch.distributed as dist
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29591")
+os.environ["MASTER_ADDR"] = "127.0.0.1"          # MASTER_PORT: a free port chosen by the parent test
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 import c3dgs_amd
@@ -257,7 +257,12 @@ def test_sharded_path_runs_on_the_nccl_backend():
     import os
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
     r = subprocess.run([sys.executable, "-c", _NCCL_CHILD], cwd=root, capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(port)))
     assert r.returncode == 0 and "NCCL_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
