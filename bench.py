@@ -13,7 +13,9 @@ autograd Function, inputs resident in HBM.  The raster path does not shard a sin
 only"), so with --gpus N every rank renders its own replica and `value` is the whole-job views/s (weak scaling).
 
 Extra objects on the same JSON line:
-  roofline      dominant kernel: algorithmic bytes per launch (SURVEY.md 8(d) formula) / live HIP-event duration
+  roofline      dominant kernel: algorithmic bytes per launch (SURVEY.md 8(d) formula) / live HIP-event duration; `traffic` = HBM
+                bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that THIS invocation runs on a child
+                copy of itself (N = 1, default flags; otherwise the committed profiles/traffic_latest.json), `traffic_source` says which
   cpu_baseline  the oracle (CPU restatement, OpenMP) timed on this box's host cores on a bounded sample
   stages        per-stage mean ms from the same HIP events (all kernels of the view)
   parity        HIP vs oracle on THIS workload at full size (integers equal, PSNR, gradient rel-inf; tests/fullsize.py),
@@ -147,6 +149,8 @@ def main():
     ap.add_argument("--no-vq", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-GPU extra lines (qat_loop, qat_model, postvq layout)")
     ap.add_argument("--vq-steps", type=int, default=30)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc passes (about 30 s); roofline.traffic then comes from profiles/traffic_latest.json")
     ap.add_argument("--selftest-launch", default=None, metavar="BACKEND", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -278,6 +282,12 @@ def main():
                           "--no-cpu-baseline --no-extras` (tools/pmc_traffic.sh; counters cannot be read inside the timed process)"
     except Exception:
         traffic_all = {}
+    # ... unless rocprofv3 is at hand: then the two PMC passes (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md, HBM) are run right
+    # here on THIS build and box, each as a child process that profiles this same script on the same workload
+    if rank == 0 and world == 1 and not args.no_live_traffic and not args.no_cpu_baseline and "C3DGS_BENCH_CHILD" not in os.environ:
+        live = live_pmc_traffic(P, W, H)
+        if live:
+            traffic_all, traffic_src = live, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script (3 steps each), run by this bench invocation"
     traffic = traffic_all.get(dom, {}).get("hbm_bytes_per_launch")
 
     def roofline_of(k):
@@ -396,6 +406,38 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def live_pmc_traffic(P, W, H):
+    """HBM bytes per launch of every raster kernel from two rocprofv3 --pmc passes (separate passes for FETCH_SIZE and
+    WRITE_SIZE, kernel trace only, units and the gfx950 x2 on FETCH_SIZE as tools/pmc_summarize.py applies them) of a child
+    run of this script. None when rocprofv3 is missing or anything goes wrong (the committed profile is used then)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_summarize
+        out = tempfile.mkdtemp(prefix="c3dgs_pmc_")
+        env = dict(os.environ, TMPDIR="/tmp", C3DGS_BENCH_CHILD="1")
+        files = {}
+        for counter, tag in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, tag), "-o", tag, "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-vq", "--no-cpu-baseline",
+                   "--no-extras", "--gaussians", str(P), "--width", str(W), "--height", str(H)]
+            subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+            import glob
+            hits = glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True)
+            if not hits:
+                return None
+            files[tag] = hits[0]
+        res = pmc_summarize.summarize(files["f"], files["w"])
+        shutil.rmtree(out, ignore_errors=True)
+        return res or None
+    except Exception:
+        return None
 
 
 def bench_postvq_layout(step, t, P, steps, dev, _lib):

@@ -29,17 +29,22 @@ def load(path, counter):
     return per
 
 
-fetch = load(sys.argv[1], "FETCH_SIZE")
-write = load(sys.argv[2], "WRITE_SIZE")
-out = {}
-for st in sorted(set(fetch) | set(write)):
-    f = fetch.get(st, [0.0])
-    w = write.get(st, [0.0])
-    # warm launches only: drop the first one
-    f = f[1:] if len(f) > 1 else f
-    w = w[1:] if len(w) > 1 else w
-    fb = 2.0 * 1024.0 * sum(f) / len(f)
-    wb = 1024.0 * sum(w) / len(w)
-    out[st] = {"hbm_bytes_per_launch": fb + wb, "fetch_bytes": fb, "write_bytes": wb, "fetch_x2_applied": True,
-               "launches_averaged": len(f)}
-print(json.dumps(out, indent=1))
+def summarize(fetch_csv, write_csv):
+    fetch = load(fetch_csv, "FETCH_SIZE")
+    write = load(write_csv, "WRITE_SIZE")
+    out = {}
+    for st in sorted(set(fetch) | set(write)):
+        f = fetch.get(st, [0.0])
+        w = write.get(st, [0.0])
+        # warm launches only: drop the first one
+        f = f[1:] if len(f) > 1 else f
+        w = w[1:] if len(w) > 1 else w
+        fb = 2.0 * 1024.0 * sum(f) / len(f)
+        wb = 1024.0 * sum(w) / len(w)
+        out[st] = {"hbm_bytes_per_launch": fb + wb, "fetch_bytes": fb, "write_bytes": wb, "fetch_x2_applied": True,
+                   "launches_averaged": len(f)}
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(summarize(sys.argv[1], sys.argv[2]), indent=1))
