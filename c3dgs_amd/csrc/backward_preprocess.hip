@@ -1,9 +1,15 @@
-// backward_preprocess.hip -- per-Gaussian backward for gfx950: ONE kernel that
-//   (a) sums the Gaussian's contiguous run of per-tile partial sums written by render_backward_kernel,
-//   (b) K11  computeCov2DCUDA        reference cuda_rasterizer/backward.cu:144-274,
-//   (c) K12  BACKWARD::preprocessCUDA reference backward.cu:346-396 (+ computeColorFromSH :20-139,
+// backward_preprocess.hip -- per-Gaussian backward for gfx950, two kernels:
+//   sum_partials_kernel (one lane per Gaussian, all P): sums the Gaussian's contiguous run of per-tile partial sums
+//       written by render_backward_kernel, zero-fills the gradient rows of every Gaussian no pixel blended and appends
+//       the others to a compact list (id + where its nine sums were parked);
+//   backward_preprocess_kernel (one lane per LISTED Gaussian, full waves):
+//       K11  computeCov2DCUDA        reference cuda_rasterizer/backward.cu:144-274,
+//       K12  BACKWARD::preprocessCUDA reference backward.cu:346-396 (+ computeColorFromSH :20-139,
 //            computeCov3D :278-341), K12i reference backward_indexed.cu:20-342.
-// It writes EVERY element of the P-sized outputs (zeros for culled Gaussians), so the caller needs
+// Only about a third of the Gaussians of a dense view are ever blended: as ONE kernel the ~600-instruction per-Gaussian
+// part ran with a third of its lanes and at the four waves per SIMD its registers allow, which also throttled the
+// streaming summation in front of it. Split, the summation runs at full occupancy and the heavy part on full waves.
+// Together they write EVERY element of the P-sized outputs (zeros for culled Gaussians), so the caller needs
 // no zero-fill of those (the reference memsets ~0.9 GB per call at P=3M, rasterize_points.cu:153-162).
 // Only the codebook-sized outputs of the indexed variant are accumulated with fp32 atomics
 // (pre-zeroed by the C-ABI entry point); atomicAdd(float*) is a single global_atomic_add_f32 on gfx950.
@@ -17,9 +23,12 @@
 #ifndef C3DGS_BWD_FG
 #define C3DGS_BWD_FG 8
 #endif
-#ifndef C3DGS_BWD_WAVES
-#define C3DGS_BWD_WAVES 4   // waves per SIMD the register allocator must reach (128 VGPRs); measured: 3 -> 0.62 ms, 4 -> 0.54, 5 -> 0.60
+#ifndef C3DGS_SUM_WAVES
+#define C3DGS_SUM_WAVES 16  // waves per workgroup of sum_partials_kernel = 64 x this many Gaussians share one list of blended ones
 #endif
+#ifndef C3DGS_BWD_WAVES
+#define C3DGS_BWD_WAVES 3   // waves per SIMD of backward_preprocess_kernel (168 VGPRs, nothing spilled); measured on one box,
+#endif                      // interleaved: 3 -> 0.153 ms, 4 (128 VGPRs, 32 spilled) -> 0.166, 5 -> 0.20
 
 namespace c3dgs {
 
@@ -30,7 +39,8 @@ struct BwdArgs {
     const float* view; const float* proj; const float* campos;
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     const int32_t* radii; const uint32_t* inst_offset; const uint32_t* block_base; const uint8_t* clamped; const float4* splat;
-    const float* partials; const uint8_t* touched;
+    float* partials; const uint8_t* touched;
+    uint32_t* live_count; uint32_t* live_ids; uint32_t* live_slots;   // the compact list (sum_partials_kernel -> backward_preprocess_kernel)
     c3dgs_raster_grads g;
 };
 
@@ -109,31 +119,26 @@ __device__ __forceinline__ void sh_backward(const float* c, float* dst, int M, c
     dmean_add[2] = (-d0.x * d0.z * ddx - d0.y * d0.z * ddy + (sum2 - d0.z * d0.z) * ddz) * invsum32;
 }
 
-template <int DEG, bool INDEXED>
-__global__ void __launch_bounds__(256)
-#if C3DGS_BWD_WAVES
-__attribute__((amdgpu_waves_per_eu(C3DGS_BWD_WAVES, C3DGS_BWD_WAVES)))
-#endif
-backward_preprocess_kernel(const BwdArgs a)
+// position of the r-th (0-based) set bit of m; r < popcount(m)
+__device__ __forceinline__ uint32_t nth_set_bit(unsigned long long m, uint32_t r)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t w = (uint32_t)m, at = 0, c = (uint32_t)__popc(w);
+    if (r >= c) { r -= c; w = (uint32_t)(m >> 32); at = 32; }
+    c = (uint32_t)__popc(w & 0xFFFFu); if (r >= c) { r -= c; w >>= 16; at += 16; }
+    c = (uint32_t)__popc(w & 0xFFu);   if (r >= c) { r -= c; w >>= 8; at += 8; }
+    c = (uint32_t)__popc(w & 0xFu);    if (r >= c) { r -= c; w >>= 4; at += 4; }
+    c = (uint32_t)__popc(w & 0x3u);    if (r >= c) { r -= c; w >>= 2; at += 2; }
+    if (r >= (w & 1u)) at += 1;
+    return at;
+}
+
+// ---- kernel 1: per-Gaussian sums of the per-tile partials, zero rows, compact list of the blended Gaussians
+__global__ void __launch_bounds__(64 * C3DGS_SUM_WAVES) sum_partials_kernel(const BwdArgs a)
+{
+    constexpr int SW = C3DGS_SUM_WAVES, LIST = 64 * SW;
+    const int i = blockIdx.x * LIST + threadIdx.x;
     const size_t si = (size_t)i;
     const c3dgs_raster_grads& o = a.g;
-    constexpr int NB = (DEG + 1) * (DEG + 1);
-
-    // Indexed variant: codebook-sized gradients are scatter-ADDED. One lane per Gaussian would issue each atomic
-    // with 64 lanes in 64 different rows, the slowest shape for the chip's memory-side float atomics
-    // (MI355X_MICROARCH.md, Global float atomics: ~17x below the contiguous rate). Instead every lane parks its
-    // factors in LDS and the wave then walks its 64 Gaussians together: one atomic instruction per Gaussian whose
-    // lanes cover that Gaussian's contiguous gradient row (up to 48 floats = 192 B for SH).
-    __shared__ float s_g[INDEXED ? 256 : 1][3];
-    __shared__ int32_t s_row[INDEXED ? 256 : 1];      // codebook rows fit int32 (SHS, GS are int32 in the ABI)
-    __shared__ float s_ds[INDEXED ? 256 : 1][3];
-    __shared__ float s_dq[INDEXED ? 256 : 1][4];
-    __shared__ int32_t s_gi[INDEXED ? 256 : 1];
-    if (INDEXED) { s_row[threadIdx.x] = -1; s_gi[threadIdx.x] = -1; }
-
-    bool live = i < a.P && a.radii[i] > 0;
 
     // ---- (a) sum each Gaussian's per-tile partials: slots [start, end) of inst_offset (id order, so the 64
     // Gaussians of a wave own ONE contiguous slot range). A per-lane loop over global memory would run as long as
@@ -141,50 +146,51 @@ backward_preprocess_kernel(const BwdArgs a)
     // through LDS in chunks with coalesced, independent loads (skipping never-written slots by their flag byte)
     // and every lane then adds up its own run from LDS. Fixed order -> still bitwise reproducible.
     constexpr int CH = C3DGS_BWD_CH;
-    // one LDS region per wave, used twice: first as the staging area of the partial sums [CH][9], later (indexed variant)
-    // as the wave's 64 rows of SH basis values [64][NB+1] for the cooperative scatter-add. A wave only ever touches its
-    // own region, so wave-level fences order the two uses.
-    constexpr int WBUF = (CH * PARTIAL_FLOATS > 64 * (NB + 1)) ? CH * PARTIAL_FLOATS : 64 * (NB + 1);
-    __shared__ float s_buf[4][WBUF];
+    // one LDS staging area per wave for the partial sums [CH][9]; a wave only ever touches its own
+    __shared__ float s_buf[C3DGS_SUM_WAVES][CH * PARTIAL_FLOATS];
 #define s_stage(w, sl, q) s_buf[w][(sl) * PARTIAL_FLOATS + (q)]
-#define s_basis(t, k) s_buf[(t) >> 6][((t) & 63) * (NB + 1) + (k)]
     // Only ~1/4 of the slots were ever written (the blend kernel stops at each tile's saturation point), so the wave
     // first reads the FLAG bytes of a whole sweep of FG*64 slots (independent byte loads, one wait), turns them into
     // per-group ballots + running counts, and stages only the WRITTEN slots, compacted: entry e of the sweep = the e-th
     // written slot. A lane's own run [start, end) maps to the contiguous entry range [below(start), below(end)), so the
     // summation loop touches no flags and one pass usually covers the wave's whole range.
     constexpr int FG = C3DGS_BWD_FG;
-    __shared__ unsigned long long s_fl[4][FG];
-    __shared__ uint32_t s_pre[4][FG + 1];
+    __shared__ unsigned long long s_fl[C3DGS_SUM_WAVES][FG];
+    __shared__ uint32_t s_pre[C3DGS_SUM_WAVES][FG + 1];
     bool any_written = false;            // did ANY pixel of ANY tile blend this Gaussian?
     float acc[PARTIAL_FLOATS];
 #pragma unroll
     for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] = 0.f;
+    const int lane_ = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane_) - 1ull;
+    uint32_t start_;
     {
-        const int lane_ = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const unsigned long long lt_mask = (1ull << lane_) - 1ull;
         const int ic = min(i, a.P - 1);                       // lanes past P clamp to the last Gaussian (empty run)
         // global slot offsets = per-workgroup inclusive offsets of the forward + block_base[] (preprocess.hip)
         const uint32_t end_ = a.inst_offset[ic] + a.block_base[ic >> 8];
-        uint32_t start_ = (ic == 0) ? 0u : a.inst_offset[ic - 1] + a.block_base[(ic - 1) >> 8];
+        start_ = (ic == 0) ? 0u : a.inst_offset[ic - 1] + a.block_base[(ic - 1) >> 8];
         if (i >= a.P) start_ = end_;
         const uint32_t w_begin = __builtin_amdgcn_readfirstlane(start_);
         const uint32_t w_end = __builtin_amdgcn_readlane(end_, 63);
         for (uint32_t base = w_begin; base < w_end; base += FG * 64) {
             const uint32_t nsl = min((uint32_t)(FG * 64), w_end - base);
             uint32_t fbits = 0;                               // bit g: slot base + 64 g + lane was written
+            uint8_t fb[FG];                                   // unconditional loads (clamped), so all FG are in flight together
 #pragma unroll
-            for (int g = 0; g < FG; g++) {
-                const uint32_t sl = (uint32_t)(g * 64 + lane_);
-                if (sl < nsl && a.touched[base + sl] != 0) fbits |= 1u << g;
-            }
+            for (int g = 0; g < FG; g++) fb[g] = a.touched[base + min((uint32_t)(g * 64 + lane_), nsl - 1u)];
+#pragma unroll
+            for (int g = 0; g < FG; g++)
+                if ((uint32_t)(g * 64 + lane_) < nsl && fb[g] != 0) fbits |= 1u << g;
             uint32_t W = 0;                                   // wave-uniform running count of written slots
+            uint32_t pre[FG + 1];                             // wave-uniform: written slots in front of group g
 #pragma unroll
             for (int g = 0; g < FG; g++) {
                 const unsigned long long bm = __ballot((fbits >> g) & 1u);
                 if (lane_ == 0) { s_fl[wv][g] = bm; s_pre[wv][g] = W; }
+                pre[g] = W;
                 W += (uint32_t)__popcll(bm);
             }
+            pre[FG] = W;
             if (W == 0) continue;                             // nothing in this sweep was ever blended
             if (lane_ == 0) s_pre[wv][FG] = W;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -199,20 +205,28 @@ backward_preprocess_kernel(const BwdArgs a)
             const uint32_t clo = below(lo), chi = below(hi);
             any_written |= chi > clo;
             for (uint32_t p0 = 0; p0 < W; p0 += CH) {
+                // Staging with the lanes on the COMPACTED entries: lane l fetches entries p0 + l, p0 + 64 + l, ... It finds
+                // its entry's slot from the ballots (group by the running counts, then the r-th set bit of that group's
+                // mask), so every load of the chunk is independent of every other and issued before the first wait --
+                // with the lanes on the raw slots, each group's loads sat behind a branch and the wave paid one memory
+                // round trip per group.
+                float st[CH / 64][PARTIAL_FLOATS];
 #pragma unroll
-                for (int g = 0; g < FG; g++) {
-                    const uint32_t pre_g = __builtin_amdgcn_readfirstlane(s_pre[wv][g]);
-                    const uint32_t pre_n = __builtin_amdgcn_readfirstlane(s_pre[wv][g + 1]);
-                    if (pre_n <= p0 || pre_g >= p0 + CH) continue;                  // wave-uniform
-                    if ((fbits >> g) & 1u) {
-                        const uint32_t e = pre_g + (uint32_t)__popcll(s_fl[wv][g] & lt_mask);
-                        if (e >= p0 && e < p0 + CH) {
-                            const float* src = a.partials + (size_t)(base + g * 64 + lane_) * PARTIAL_FLOATS;
+                for (int h = 0; h < CH / 64; h++) {
+                    const uint32_t e = min(p0 + (uint32_t)(h * 64 + lane_), W - 1u);   // clamped: always a real entry
+                    uint32_t g = 0, r = e;
 #pragma unroll
-                            for (int q = 0; q < PARTIAL_FLOATS; q++) s_stage(wv, e - p0, q) = src[q];
-                        }
-                    }
+                    for (int k = 1; k < FG; k++)
+                        if (e >= pre[k]) { g = (uint32_t)k; r = e - pre[k]; }
+                    const uint32_t slot = g * 64u + nth_set_bit(s_fl[wv][g], r);
+                    const float* src = a.partials + (size_t)(base + slot) * PARTIAL_FLOATS;
+#pragma unroll
+                    for (int q = 0; q < PARTIAL_FLOATS; q++) st[h][q] = src[q];
                 }
+#pragma unroll
+                for (int h = 0; h < CH / 64; h++)
+#pragma unroll
+                    for (int q = 0; q < PARTIAL_FLOATS; q++) s_stage(wv, h * 64 + lane_, q) = st[h][q];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -226,29 +240,154 @@ backward_preprocess_kernel(const BwdArgs a)
             }
         }
     }
-    // A Gaussian none of whose tile instances was ever blended (it sits behind every pixel's saturation point: the
-    // majority on dense scenes) has exactly zero gradients: it takes the cheap zero-fill path, i.e. no SH / codebook
-    // gathers, no scatter-adds. Same values as the reference, which adds nothing for it.
-    const bool live_in = live;
-    live = live_in && any_written;
-    if (i < a.P && !live) {                // culled or never blended: all-zero gradient rows
+    // A Gaussian none of whose tile instances was ever blended (culled, or behind every pixel's saturation point: the
+    // majority on dense scenes) has exactly zero gradients: zero rows here, no SH / codebook gathers, no scatter-adds.
+    // Same values as the reference, which adds nothing for it. (any_written implies i < P and radii[i] > 0.)
+    const bool live = any_written;
+    if (i < a.P && !live) {
         if (o.dL_dmeans2D) { o.dL_dmeans2D[3 * si] = 0.f; o.dL_dmeans2D[3 * si + 1] = 0.f; o.dL_dmeans2D[3 * si + 2] = 0.f; }
         if (o.dL_dcolors) { o.dL_dcolors[3 * si] = 0.f; o.dL_dcolors[3 * si + 1] = 0.f; o.dL_dcolors[3 * si + 2] = 0.f; }
         if (o.dL_dopacity) o.dL_dopacity[si] = 0.f;
         if (o.dL_dmeans3D) { o.dL_dmeans3D[3 * si] = 0.f; o.dL_dmeans3D[3 * si + 1] = 0.f; o.dL_dmeans3D[3 * si + 2] = 0.f; }
         if (o.dL_dcov3D) for (int q = 0; q < 6; q++) o.dL_dcov3D[6 * si + q] = 0.f;
         if (o.dL_dscale_factors) o.dL_dscale_factors[si] = 0.f;
-        if (!INDEXED) {
+        if (!a.sh_indices && !a.g_indices) {                  // non-indexed: per-Gaussian rows
             if (o.dL_dsh && a.sh) for (int q = 0; q < a.M * 3; q++) o.dL_dsh[si * a.M * 3 + q] = 0.f;
             if (o.dL_dscales && a.scales) for (int q = 0; q < 3; q++) o.dL_dscales[3 * si + q] = 0.f;
             if (o.dL_drotations && a.scales) for (int q = 0; q < 4; q++) o.dL_drotations[4 * si + q] = 0.f;
         }
     }
+    // The blended ones go on the workgroup's list (256 entries per workgroup, filled from the front, in id order; a single
+    // global list would cost one same-address atomic per wave). The nine sums are parked in the Gaussian's own FIRST slot
+    // of the partial-sum array (only this wave reads this wave's slots, and it is done with them).
+    __shared__ uint32_t s_cnt[SW];
+    const unsigned long long lm = __ballot(live);
+    if (lane_ == 0) s_cnt[wv] = (uint32_t)__popcll(lm);
+    __syncthreads();
+    uint32_t run0 = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < SW; w++) { const uint32_t c = s_cnt[w]; run0 += (w < wv) ? c : 0u; all += c; }
     if (live) {
+        const size_t pos = (size_t)blockIdx.x * LIST + run0 + (uint32_t)__popcll(lm & lt_mask);
+        a.live_ids[pos] = (uint32_t)i;
+        a.live_slots[pos] = start_;
+        float* dst = a.partials + (size_t)start_ * PARTIAL_FLOATS;
+#pragma unroll
+        for (int q = 0; q < PARTIAL_FLOATS; q++) dst[q] = acc[q];
+    }
+    if (threadIdx.x == 0) a.live_count[blockIdx.x] = all;
+}
+#undef s_stage
+
+// ---- kernel 2: the blended Gaussians, one lane each, in list order
+template <int DEG, bool INDEXED>
+__global__ void __launch_bounds__(256)
+#if C3DGS_BWD_WAVES
+__attribute__((amdgpu_waves_per_eu(C3DGS_BWD_WAVES, C3DGS_BWD_WAVES)))
+#endif
+backward_preprocess_kernel(const BwdArgs a, const float* __restrict__ cam_view, const float* __restrict__ cam_proj,
+                           const float* __restrict__ cam_pos)   // the camera as direct restrict parameters: scalar loads
+{
+    // the workgroup's list fills whole waves from the front: a wave past its end has nothing to do (waves are independent:
+    // no workgroup barrier below)
+    // Workgroup -> (list, quarter of the list): all FIRST quarters come first in the grid, then all second ones, ...
+    // Lists fill from the front, so the populated quarters are spread evenly over the XCDs (consecutive workgroups go to
+    // consecutive XCDs; quarter = blockIdx % 4 would send every full quarter to the same two of the eight) and the
+    // mostly empty ones come last.
+    const uint32_t n_lists = gridDim.x / (C3DGS_SUM_WAVES / 4);
+    const uint32_t list = blockIdx.x % n_lists, quarter = blockIdx.x / n_lists;
+    const uint32_t n_live = a.live_count[list];
+    const uint32_t off = quarter * 256u + threadIdx.x;
+    if ((off & ~63u) >= n_live) return;
+    const size_t pos = (size_t)list * (64 * C3DGS_SUM_WAVES) + off;
+    const bool live = off < n_live;
+    const int i = live ? (int)a.live_ids[pos] : 0;
+    const size_t si = (size_t)i;
+    const c3dgs_raster_grads& o = a.g;
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+
+    // Indexed variant: codebook-sized gradients are scatter-ADDED. One lane per Gaussian would issue each atomic
+    // with 64 lanes in 64 different rows, the slowest shape for the chip's memory-side float atomics
+    // (MI355X_MICROARCH.md, Global float atomics: ~17x below the contiguous rate). Instead every lane parks its
+    // factors in LDS and the wave then walks its 64 Gaussians together: one atomic instruction per Gaussian whose
+    // lanes cover that Gaussian's contiguous gradient row (up to 48 floats = 192 B for SH).
+    __shared__ float s_g[INDEXED ? 256 : 1][3];
+    __shared__ int32_t s_row[INDEXED ? 256 : 1];      // codebook rows fit int32 (SHS, GS are int32 in the ABI)
+    __shared__ float s_ds[INDEXED ? 256 : 1][3];
+    __shared__ float s_dq[INDEXED ? 256 : 1][4];
+    __shared__ int32_t s_gi[INDEXED ? 256 : 1];
+    __shared__ float s_bas[INDEXED ? 256 : 1][NB + 1];  // SH basis values of the workgroup's Gaussians
+#define s_basis(t, k) s_bas[t][k]
+    if (INDEXED) { s_row[threadIdx.x] = -1; s_gi[threadIdx.x] = -1; }
+
+    if (live) {
+    // Memory round trips are what this kernel's time is made of (random rows, four waves per SIMD), so the loads are
+    // issued by dependency LEVEL, not where the arithmetic wants them: (1) everything addressed by the Gaussian's id or
+    // slot, together; (2) the codebook rows addressed by what (1) returned, together; then the arithmetic, SH first so
+    // that its 48 coefficients leave the registers early. As the reference orders them, the same loads form a chain of
+    // seven dependent round trips.
+    float acc[PARTIAL_FLOATS];
+    {
+        const float* src = a.partials + (size_t)a.live_slots[pos] * PARTIAL_FLOATS;
+#pragma unroll
+        for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] = src[q];
+    }
+    const float4 rec0 = a.splat[3 * si], rec1 = a.splat[3 * si + 1];
+    const f3 m = { a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2] };
+    const uint8_t cl = a.clamped[i];
+    size_t gi = si, row = si;
+    float sf = 1.f;
+    if (INDEXED) {
+        if (a.g_indices) gi = (size_t)a.g_indices[i];
+        if (a.scale_factors) sf = a.scale_factors[i];
+        if (a.sh_indices) row = (size_t)a.sh_indices[i];
+    }
+    // level 2
+    float sc[3] = { 0, 0, 0 };
+    float4 rot = make_float4(1, 0, 0, 0);
+    float cov3D[6];
+    if (a.cov3D_precomp) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) cov3D[q] = a.cov3D_precomp[6 * si + q];
+    } else {
+        sc[0] = a.scales[3 * gi]; sc[1] = a.scales[3 * gi + 1]; sc[2] = a.scales[3 * gi + 2];
+        rot = *reinterpret_cast<const float4*>(a.rotations + 4 * gi);
+    }
+    constexpr int NC = (DEG + 1) * (DEG + 1) * 3;
+    float c[NC];
+    if (a.sh) {
+        const float* shp = a.sh + row * (size_t)a.M * 3;
+        if ((a.M * 3) % 4 == 0 && NC % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < NC / 4; q++) {
+                const float4 v = reinterpret_cast<const float4*>(shp)[q];
+                c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NC; q++) c[q] = shp[q];
+        }
+    }
+
+    // ---- SH (backward.cu:20-139 / backward_indexed.cu:20-201); its share of dL/dmean is added further down, where the
+    // reference adds it
+    float sh_add[3] = { 0.f, 0.f, 0.f };
+    if (a.sh) {
+        const float g[3] = { (cl & 1) ? 0.f : acc[0], (cl & 2) ? 0.f : acc[1], (cl & 4) ? 0.f : acc[2] };
+        const f3 d0 = { m.x - cam_pos[0], m.y - cam_pos[1], m.z - cam_pos[2] };
+        float* dst = o.dL_dsh ? o.dL_dsh + row * (size_t)a.M * 3 : nullptr;
+        float basis[NB];
+        sh_backward<DEG, INDEXED>(c, dst, a.M, d0, g, sh_add, basis);
+        if (INDEXED && o.dL_dsh) {
+#pragma unroll
+            for (int k = 0; k < NB; k++) s_basis(threadIdx.x, k) = basis[k];
+            s_g[threadIdx.x][0] = g[0]; s_g[threadIdx.x][1] = g[1]; s_g[threadIdx.x][2] = g[2];
+            s_row[threadIdx.x] = (int32_t)row;
+        }
+    }
 
     // acc = {sum alpha*T*dL_dpix (3), S0, Sx, Sy, Sxx, Sxy, Syy}: moments of w = G*dL_dalpha about the 2D mean
     // (render.hip). The reference's per-pair products (backward.cu:538-554) are linear in them:
-    const float4 rec0 = a.splat[3 * si], rec1 = a.splat[3 * si + 1];
     const float k_a = rec0.z, k_b = rec0.w, k_c = rec1.x, opac = rec1.y;
     const float dcol[3] = { acc[0], acc[1], acc[2] };
     const float d2x = -0.5f * (float)a.W * opac * (k_a * acc[4] + k_b * acc[5]);
@@ -259,24 +398,11 @@ backward_preprocess_kernel(const BwdArgs a)
     if (o.dL_dmeans2D) { o.dL_dmeans2D[3 * si] = d2x; o.dL_dmeans2D[3 * si + 1] = d2y; o.dL_dmeans2D[3 * si + 2] = 0.f; }
     if (o.dL_dopacity) o.dL_dopacity[si] = acc[8];
 
-    const f3 m = { a.means3D[3 * si], a.means3D[3 * si + 1], a.means3D[3 * si + 2] };
-
     // ---- (b) conic -> cov2D -> cov3D / mean (backward.cu:144-274) in matrix form:
     // A = upper 2x3 of J*R_w2c (reference T[i][j] == A[i][j]); cov2D = A*Sigma*A^T + 0.3*I.
-    float cov3D[6];
-    float sc[3] = { 0, 0, 0 }, sf = 1.f;
-    float4 rot = make_float4(1, 0, 0, 0);
-    size_t gi = si;
-    if (a.cov3D_precomp) {
-#pragma unroll
-        for (int q = 0; q < 6; q++) cov3D[q] = a.cov3D_precomp[6 * si + q];
-    } else {
-        if (INDEXED) { gi = (size_t)a.g_indices[i]; sf = a.scale_factors[i]; }
-        sc[0] = a.scales[3 * gi]; sc[1] = a.scales[3 * gi + 1]; sc[2] = a.scales[3 * gi + 2];
-        rot = *reinterpret_cast<const float4*>(a.rotations + 4 * gi);
+    if (!a.cov3D_precomp)
         cov3d_from_scale_rot(sc[0], sc[1], sc[2], INDEXED ? sf * a.scale_modifier : a.scale_modifier, rot, cov3D);
-    }
-    const Cov2D cv = cov2d(m, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.view);
+    const Cov2D cv = cov2d(m, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, cam_view);
     const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
     const float x_grad_mul = (cv.txtz < -limx || cv.txtz > limx) ? 0.f : 1.f;
     const float y_grad_mul = (cv.tytz < -limy || cv.tytz > limy) ? 0.f : 1.f;
@@ -321,7 +447,7 @@ backward_preprocess_kernel(const BwdArgs a)
         dA[0][v] = 2 * AS[0][v] * dL_da + AS[1][v] * dL_db;
         dA[1][v] = 2 * AS[1][v] * dL_dc + AS[0][v] * dL_db;
     }
-    const float* view = a.view;
+    const float* view = cam_view;
     const float dJ00 = view[0] * dA[0][0] + view[4] * dA[0][1] + view[8] * dA[0][2];
     const float dJ02 = view[2] * dA[0][0] + view[6] * dA[0][1] + view[10] * dA[0][2];
     const float dJ11 = view[1] * dA[1][0] + view[5] * dA[1][1] + view[9] * dA[1][2];
@@ -336,7 +462,7 @@ backward_preprocess_kernel(const BwdArgs a)
                        view[8] * dtx + view[9] * dty + view[10] * dtz };
 
     // ---- (c) projection of the 2D mean (backward.cu:370-387)
-    const float* proj = a.proj;
+    const float* proj = cam_proj;
     const float4 mh = xform4x4(m, proj);
     const float m_w = 1.0f / (mh.w + 0.0000001f);
     const float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
@@ -345,37 +471,7 @@ backward_preprocess_kernel(const BwdArgs a)
     dmean[1] += (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
     dmean[2] += (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
 
-    // ---- SH (backward.cu:20-139 / backward_indexed.cu:20-201)
-    if (a.sh) {
-        const size_t row = INDEXED ? (size_t)a.sh_indices[i] : si;
-        const float* shp = a.sh + row * (size_t)a.M * 3;
-        constexpr int NC = (DEG + 1) * (DEG + 1) * 3;
-        float c[NC];
-        if ((a.M * 3) % 4 == 0 && NC % 4 == 0) {
-#pragma unroll
-            for (int q = 0; q < NC / 4; q++) {
-                const float4 v = reinterpret_cast<const float4*>(shp)[q];
-                c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < NC; q++) c[q] = shp[q];
-        }
-        const uint8_t cl = a.clamped[i];
-        const float g[3] = { (cl & 1) ? 0.f : dcol[0], (cl & 2) ? 0.f : dcol[1], (cl & 4) ? 0.f : dcol[2] };
-        const f3 d0 = { m.x - a.campos[0], m.y - a.campos[1], m.z - a.campos[2] };
-        float add[3];
-        float* dst = o.dL_dsh ? o.dL_dsh + row * (size_t)a.M * 3 : nullptr;
-        float basis[NB];
-        sh_backward<DEG, INDEXED>(c, dst, a.M, d0, g, add, basis);
-        dmean[0] += add[0]; dmean[1] += add[1]; dmean[2] += add[2];
-        if (INDEXED && o.dL_dsh) {
-#pragma unroll
-            for (int k = 0; k < NB; k++) s_basis(threadIdx.x, k) = basis[k];
-            s_g[threadIdx.x][0] = g[0]; s_g[threadIdx.x][1] = g[1]; s_g[threadIdx.x][2] = g[2];
-            s_row[threadIdx.x] = (int32_t)row;
-        }
-    }
+    dmean[0] += sh_add[0]; dmean[1] += sh_add[1]; dmean[2] += sh_add[2];
     if (o.dL_dmeans3D) { o.dL_dmeans3D[3 * si] = dmean[0]; o.dL_dmeans3D[3 * si + 1] = dmean[1]; o.dL_dmeans3D[3 * si + 2] = dmean[2]; }
 
     // ---- scale / rotation (backward.cu:278-341 / backward_indexed.cu:206-282), against the standard
@@ -426,7 +522,10 @@ backward_preprocess_kernel(const BwdArgs a)
     } // live
 
     if (INDEXED) {
-        __syncthreads();
+        // each wave scatter-adds its own 64 rows: wave-level ordering of the LDS traffic is all that is needed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
         if (o.dL_dsh && a.sh) {
             const int k = lane / 3, ch = lane - 3 * k;
@@ -457,7 +556,8 @@ backward_preprocess_kernel(const BwdArgs a)
 }
 
 void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* radii, const GeomPtrs& g,
-                                const float* partials, const uint8_t* touched, const c3dgs_raster_grads& gr, hipStream_t s)
+                                float* partials, const uint8_t* touched, uint32_t* live_count, uint32_t* live_ids,
+                                uint32_t* live_slots, const c3dgs_raster_grads& gr, hipStream_t s)
 {
     if (p.P <= 0) return;
     BwdArgs a;
@@ -471,13 +571,17 @@ void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* rad
     a.scale_modifier = p.scale_modifier;
     a.radii = radii; a.inst_offset = g.inst_offset; a.block_base = g.block_base; a.clamped = g.clamped; a.splat = g.splat;
     a.partials = partials; a.touched = touched; a.g = gr;
-    const dim3 grid((p.P + 255) / 256), block(256);
+    a.live_count = live_count; a.live_ids = live_ids; a.live_slots = live_slots;
+    constexpr int LIST = 64 * C3DGS_SUM_WAVES;
+    const int n_lists = (p.P + LIST - 1) / LIST;
+    sum_partials_kernel<<<n_lists, LIST, 0, s>>>(a);
+    const dim3 grid(n_lists * (LIST / 256)), block(256);
     const bool indexed = p.sh_indices != nullptr || p.g_indices != nullptr;
     const int deg = p.sh ? p.D : 0;
 #define C3DGS_LAUNCH(DEG)                                                                     \
     do {                                                                                      \
-        if (indexed) backward_preprocess_kernel<DEG, true><<<grid, block, 0, s>>>(a);         \
-        else backward_preprocess_kernel<DEG, false><<<grid, block, 0, s>>>(a);                \
+        if (indexed) backward_preprocess_kernel<DEG, true><<<grid, block, 0, s>>>(a, a.view, a.proj, a.campos);         \
+        else backward_preprocess_kernel<DEG, false><<<grid, block, 0, s>>>(a, a.view, a.proj, a.campos);                \
     } while (0)
     switch (deg) {
         case 0: C3DGS_LAUNCH(0); break;
@@ -488,7 +592,6 @@ void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* rad
 #undef C3DGS_LAUNCH
 }
 
-#undef s_stage
 #undef s_basis
 
 } // namespace c3dgs

@@ -208,14 +208,22 @@ static int backward_impl(const c3dgs_raster_params* pp, bool indexed, const int3
     const int P = p.P, W = p.W, H = p.H;
 
     // codebook-sized outputs of the indexed variant are scatter-added: zero them here
+    void* cb_zero = nullptr;           // one 16-byte aligned span of whole 16-byte words: cleared by the prep kernel below
+    size_t cb_zero16 = 0;
     if (indexed) {
         const size_t n_sh = (grads->dL_dsh && p.sh) ? (size_t)p.SHS * p.M * 3 * sizeof(float) : 0;
         const size_t n_rot = (grads->dL_drotations && p.scales) ? (size_t)p.GS * 4 * sizeof(float) : 0;
         const size_t n_sc = (grads->dL_dscales && p.scales) ? (size_t)p.GS * 3 * sizeof(float) : 0;
         char* a_sh = (char*)grads->dL_dsh; char* a_rot = (char*)grads->dL_drotations; char* a_sc = (char*)grads->dL_dscales;
         if (n_sh && n_rot && n_sc && a_rot == a_sh + n_sh && a_sc == a_rot + n_rot) {
-            // the three tensors are carved from one allocation (c3dgs_amd/rasterizer.py does that): one fill launch
-            C3DGS_HIP_TRY(hipMemsetAsync(a_sh, 0, n_sh + n_rot + n_sc, s));
+            // the three tensors are carved from one allocation (c3dgs_amd/rasterizer.py does that): one fill
+            const size_t n = n_sh + n_rot + n_sc;
+            if (p.P > 0 && R >= 0 && ((uintptr_t)a_sh & 15u) == 0) {
+                cb_zero = a_sh; cb_zero16 = n / 16;
+                if (n % 16) C3DGS_HIP_TRY(hipMemsetAsync(a_sh + cb_zero16 * 16, 0, n % 16, s));
+            } else {
+                C3DGS_HIP_TRY(hipMemsetAsync(a_sh, 0, n, s));
+            }
         } else {
             if (n_sh) C3DGS_HIP_TRY(hipMemsetAsync(a_sh, 0, n_sh, s));
             if (n_sc) C3DGS_HIP_TRY(hipMemsetAsync(a_sc, 0, n_sc, s));
@@ -235,17 +243,26 @@ static int backward_impl(const c3dgs_raster_params* pp, bool indexed, const int3
     if (!partials) return fail(C3DGS_E_ALLOC, "backward workspace allocation failed");
 
     // only the 1-byte "written" flags are cleared (R bytes, not 36 R): the blend kernel never visits the instances
-    // behind each tile's saturation point (73 % of them on the bench scene) and the per-Gaussian kernel skips them
-    uint8_t* touched = (uint8_t*)partials + align_up((size_t)(R > 0 ? R : 1) * PARTIAL_FLOATS * sizeof(float));
-    { StageTimer t_(ST_ZERO_PARTIALS, s); C3DGS_HIP_TRY(hipMemsetAsync(touched, 0, (size_t)(R > 0 ? R : 1), s)); }
+    // behind each tile's saturation point (73 % of them on the bench scene) and the per-Gaussian kernel skips them.
+    // Workspace: partial sums | flags | tile schedule | per-workgroup lists of the blended Gaussians (id, slot) and their lengths
+    const size_t r1 = (size_t)(R > 0 ? R : 1), p256 = ((size_t)P + 1023) / 1024 * 1024;   // whole lists (<= 1024 entries each)
+    uint8_t* touched = (uint8_t*)partials + align_up(r1 * PARTIAL_FLOATS * sizeof(float));
+    uint32_t* tile_order = (uint32_t*)(touched + align_up(r1));
+    uint32_t* live_ids = tile_order + 65536;
+    uint32_t* live_slots = live_ids + p256;
+    uint32_t* live_count = live_slots + p256;
+    // one launch: tile schedule of the blend kernel + the flag clear + the codebook-gradient clear
+    { StageTimer t_(ST_ZERO_PARTIALS, s);
+      launch_backward_prep(R > 0 ? W : 0, H, img, tile_order, touched, align_up(r1) / 16, cb_zero, cb_zero16, s); }
     if (R > 0) {
         const BinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), R, W, H);
         { StageTimer t_(ST_RENDER_BWD, s);
           launch_render_backward(W, H, img, b.point_list, g.splat, g.block_base, p.background, dL_dout_color, partials, touched,
-                                 (const uint8_t*)b.sort_temp, (uint32_t*)(touched + align_up((size_t)(R > 0 ? R : 1))), s); } // K10
+                                 (const uint8_t*)b.sort_temp, tile_order, s); } // K10
         C3DGS_STAGE("render_backward", p.debug, s);
     }
-    { StageTimer t_(ST_BWD_PREPROCESS, s); launch_backward_preprocess(p, radii, g, partials, touched, *grads, s); } // K11 + K12(i)
+    { StageTimer t_(ST_BWD_PREPROCESS, s);
+      launch_backward_preprocess(p, radii, g, partials, touched, live_count, live_ids, live_slots, *grads, s); } // K11 + K12(i)
     C3DGS_STAGE("backward_preprocess", p.debug, s);
     return C3DGS_OK;
 }
@@ -354,10 +371,11 @@ int c3dgs_get_image_layout(int32_t W, int32_t H, c3dgs_image_layout* out)
 }
 size_t c3dgs_backward_workspace_bytes(int32_t P, int32_t R)
 {
-    (void)P;
-    const size_t r = (size_t)(R > 0 ? R : 1);
-    // partial sums + 1-byte written flags + the backward's tile schedule (at most 65536 tiles)
-    return align_up(r * PARTIAL_FLOATS * sizeof(float)) + align_up(r) + 65536 * sizeof(uint32_t);
+    const size_t r = (size_t)(R > 0 ? R : 1), p256 = ((size_t)(P > 0 ? P : 1) + 1023) / 1024 * 1024;
+    // partial sums + 1-byte written flags + the backward's tile schedule (at most 65536 tiles) + the per-workgroup lists of
+    // blended Gaussians (id, slot of its sums: 256 entries per workgroup) + their lengths
+    return align_up(r * PARTIAL_FLOATS * sizeof(float)) + align_up(r) + 65536 * sizeof(uint32_t) +
+           (2 * p256 + p256 / 256) * sizeof(uint32_t) + 256;
 }
 
 int c3dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

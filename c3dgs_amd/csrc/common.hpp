@@ -167,12 +167,15 @@ hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin
 // render.hip
 void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                            const float* bg, float* out_color, uint8_t* qmask, const uint32_t* sort_err, hipStream_t s);
+void launch_backward_prep(int W, int H, const ImgPtrs& img, uint32_t* tile_order, void* zero_a, size_t n16_a, void* zero_b,
+                          size_t n16_b, hipStream_t s);
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                             const uint32_t* block_base, const float* bg, const float* dL_dpix, float* partials,
-                            uint8_t* touched, const uint8_t* qmask, uint32_t* tile_order, hipStream_t s);
+                            uint8_t* touched, const uint8_t* qmask, const uint32_t* tile_order, hipStream_t s);
 // backward_preprocess.hip
 void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* radii, const GeomPtrs& g,
-                                const float* partials, const uint8_t* touched, const c3dgs_raster_grads& gr, hipStream_t s);
+                                float* partials, const uint8_t* touched, uint32_t* live_count, uint32_t* live_ids,
+                                uint32_t* live_slots, const c3dgs_raster_grads& gr, hipStream_t s);
 // vq.hip
 int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const int64_t* gather, const float* codebook,
                              float* out_dist, int64_t* out_idx, hipStream_t s, int* flag_list = nullptr, int flag_cap = 0);

@@ -276,24 +276,53 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
 // device->host read of num_rendered brings it along (radix_sort.hip).
 __global__ void __launch_bounds__(1024) scan_blocks_kernel(int nb, uint32_t* __restrict__ base, const uint32_t* __restrict__ sort_err)
 {
+    // One workgroup; a thread owns 16 CONSECUTIVE totals (four independent 16-byte loads), so 16384 totals cost one
+    // memory round trip and one barrier. (One total per thread and a round trip + barrier per 1024 totals took 12 us for the
+    // 11.7k totals of P = 3M: pure latency.) `base` is 256-byte aligned with room up to the next multiple of 16 entries + 2.
     __shared__ uint32_t s_w[2][16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     uint32_t carry = 0;                                   // every thread tracks the running total itself
     int buf = 0;
-    for (int c0 = 0; c0 < nb; c0 += 1024, buf ^= 1) {
-        const int idx = c0 + t;
-        const uint32_t v = idx < nb ? base[idx] : 0u;
-        uint32_t incl = v;
+    for (int c0 = 0; c0 < nb; c0 += 16384, buf ^= 1) {
+        const int i0 = c0 + t * 16;
+        uint32_t v[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint4 x = make_uint4(0u, 0u, 0u, 0u);
+            if (i0 + 4 * q + 3 < nb) x = reinterpret_cast<const uint4*>(base + i0)[q];
+            else {
+                if (i0 + 4 * q < nb) x.x = base[i0 + 4 * q];
+                if (i0 + 4 * q + 1 < nb) x.y = base[i0 + 4 * q + 1];
+                if (i0 + 4 * q + 2 < nb) x.z = base[i0 + 4 * q + 2];
+            }
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) mine += v[q];
+        uint32_t incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
         if (lane == 63) s_w[buf][wave] = incl;
-        __syncthreads();                                  // one barrier per 1024 totals (s_w is double-buffered)
+        __syncthreads();                                  // s_w is double-buffered: one barrier per sweep
         uint32_t off = carry, all = 0;
 #pragma unroll
         for (int w = 0; w < 16; w++) { const uint32_t x = s_w[buf][w]; if (w < wave) off += x; all += x; }
-        if (idx < nb) base[idx] = off + incl - v;
+        uint32_t run = off + incl - mine;                 // exclusive base of this thread's first total
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const uint32_t x = v[q]; v[q] = run; run += x; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (i0 + 4 * q + 3 < nb) reinterpret_cast<uint4*>(base + i0)[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            else {
+                if (i0 + 4 * q < nb) base[i0 + 4 * q] = v[4 * q];
+                if (i0 + 4 * q + 1 < nb) base[i0 + 4 * q + 1] = v[4 * q + 1];
+                if (i0 + 4 * q + 2 < nb) base[i0 + 4 * q + 2] = v[4 * q + 2];
+            }
+        }
         carry += all;
     }
+    __syncthreads();                                      // the last sweep's stores precede the two words behind them
     if (t == 0) {
         base[nb] = carry;
         if (sort_err) base[nb + 1] = *sort_err;
@@ -421,24 +450,34 @@ void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int 
 __global__ void __launch_bounds__(256)
 identify_ranges_kernel(int L, const uint16_t* __restrict__ keys, uint2* __restrict__ ranges)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= L) return;
-    const uint32_t cur = keys[idx];
-    if (idx == 0) ranges[cur].x = 0;
-    else {
-        const uint32_t prev = keys[idx - 1];
-        if (cur != prev) {
-            ranges[prev].y = (uint32_t)idx;
-            ranges[cur].x = (uint32_t)idx;
+    // eight sorted keys per thread (one 16-byte load + the key in front of them): the buffer is 256-byte aligned and
+    // padded, so the last thread's load stays inside it
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = j * 8;
+    if (i0 >= L) return;
+    const uint4 v = reinterpret_cast<const uint4*>(keys)[j];
+    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+    uint32_t prev = i0 > 0 ? (uint32_t)keys[i0 - 1] : 0xffffffffu;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int idx = i0 + e;
+        if (idx < L) {
+            const uint32_t cur = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+            if (cur != prev) {
+                if (idx > 0) ranges[prev].y = (uint32_t)idx;
+                ranges[cur].x = (uint32_t)idx;
+            }
+            if (idx == L - 1) ranges[cur].y = (uint32_t)L;
+            prev = cur;
         }
     }
-    if (idx == L - 1) ranges[cur].y = (uint32_t)L;
 }
 
 void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, hipStream_t s)
 {
     if (R <= 0) return;
-    identify_ranges_kernel<<<(R + 255) / 256, 256, 0, s>>>(R, keys_sorted, ranges);
+    const int threads = (R + 7) / 8;
+    identify_ranges_kernel<<<(threads + 255) / 256, 256, 0, s>>>(R, keys_sorted, ranges);
 }
 
 } // namespace c3dgs

@@ -20,6 +20,7 @@
 //    then sums a contiguous run of slots. Plain stores run ~4-5x the chip-wide float-atomic rate on MI355X and the
 //    result is bitwise reproducible (the reference's 9 atomics per pixel-Gaussian pair, backward.cu:523-554, are not).
 #include "common.hpp"
+#include <algorithm>
 
 namespace c3dgs {
 
@@ -93,9 +94,20 @@ __device__ __forceinline__ int tile_of_block(int b, int T)
 // Tile schedule of the backward: tiles in descending order of the work they carry (tile_used = entries the tile really
 // visits, known from the forward), so that the last workgroups to start are the short ones: -3 % on the bench scene.
 // (The forward only knows its list lengths in advance; ordering it by those measured slower than the XCD-banded order.)
-// One workgroup: counting sort on tile_used / 8 (1024 buckets).
-__global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint32_t* __restrict__ tile_used, uint32_t* __restrict__ order)
+// One workgroup: counting sort on tile_used / 8 (1024 buckets). The same launch clears what the backward needs cleared (the
+// written flags of the partial sums, the scatter-added codebook gradients): workgroup 0 orders the tiles, the others
+// fill -- one launch instead of a 9 us single-workgroup kernel behind two or three fill launches.
+__global__ void __launch_bounds__(1024) backward_prep_kernel(int T, const uint32_t* __restrict__ tile_used, uint32_t* __restrict__ order,
+                                                              uint4* __restrict__ zero_a, size_t n16_a, uint4* __restrict__ zero_b, size_t n16_b)
 {
+    if (blockIdx.x > 0) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        const size_t stride = (size_t)(gridDim.x - 1) * 1024;
+        for (size_t i = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < n16_a; i += stride) zero_a[i] = z;
+        for (size_t i = (size_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < n16_b; i += stride) zero_b[i] = z;
+        return;
+    }
+    if (T <= 0) return;
     auto work = [&](int i) { return tile_used[i]; };
     __shared__ uint32_t s_cnt[1024], s_w[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -537,13 +549,24 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     }
 }
 
+// tile schedule + the backward's fills in one launch; zero_a / zero_b: 16-byte aligned spans of n16 x 16 bytes (or null / 0)
+void launch_backward_prep(int W, int H, const ImgPtrs& img, uint32_t* tile_order, void* zero_a, size_t n16_a, void* zero_b,
+                          size_t n16_b, hipStream_t s)
+{
+    const int T = (W > 0 && H > 0 && tile_order) ? tiles_x(W) * tiles_y(H) : 0;
+    const size_t n16 = n16_a + n16_b;
+    if (T <= 0 && n16 == 0) return;
+    // fill workgroups: 16 KB each per sweep, at most four per CU
+    const unsigned fill = n16 ? (unsigned)std::min<size_t>((n16 + 1023) / 1024, 1024) : 0u;
+    backward_prep_kernel<<<1 + fill, 1024, 0, s>>>(T, img.tile_used, tile_order, (uint4*)zero_a, n16_a, (uint4*)zero_b, n16_b);
+}
+
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                             const uint32_t* block_base, const float* bg, const float* dL_dpix, float* partials,
-                            uint8_t* touched, const uint8_t* qmask, uint32_t* tile_order, hipStream_t s)
+                            uint8_t* touched, const uint8_t* qmask, const uint32_t* tile_order, hipStream_t s)
 {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     const int grid = ((T + 7) / 8) * 8;
-    tile_order_kernel<<<1, 1024, 0, s>>>(T, img.tile_used, tile_order);
     render_backward_kernel<<<grid, 256, 0, s>>>(W, H, gx, T, img.ranges, img.tile_used, point_list, splat, block_base, bg, img.final_T,
                                                 img.n_contrib, dL_dpix, partials, touched, qmask, tile_order);
 }

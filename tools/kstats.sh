@@ -1,12 +1,15 @@
 #!/bin/bash
-# Per-kernel average durations of a few fwd+bwd passes (rocprofv3 --kernel-trace --stats). bash tools/kstats.sh
+# per-kernel average times of a few fwd+bwd passes of the bench workload (rocprofv3 --kernel-trace --stats). bash tools/kstats.sh [tag]
 export TMPDIR=/tmp
-cd "${GRAFT_REPO_ROOT:-$(pwd)}"
-rm -rf gpurun_out/kstats; mkdir -p gpurun_out/kstats
-ITERS=8 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats -o k -- python3 tools/prof_raster.py > gpurun_out/kstats/log.txt 2>&1
-python3 - <<'PY'
-import csv, glob
-f = glob.glob("gpurun_out/kstats/*kernel_stats.csv")[0]
-for r in list(csv.DictReader(open(f)))[:24]:
-    print(f"{float(r['AverageNs'])/1e3:9.1f} us x{r['Calls']:>4}  {r['Name'][:90]}")
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$R"
+TAG=${1:-k}
+rm -rf gpurun_out/kstats_$TAG
+ITERS=${ITERS:-6} rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats_$TAG -o k -- python3 tools/prof_raster.py > gpurun_out/kstats_$TAG.log 2>&1
+python3 - "$TAG" <<'PY'
+import csv, sys
+tag = sys.argv[1]
+rows = list(csv.DictReader(open(f"gpurun_out/kstats_{tag}/k_kernel_stats.csv")))
+for r in rows[:16]:
+    print(f"{float(r['AverageNs'])/1e6:8.4f} ms x{r['Calls']:>4}  {r['Name'][:90]}")
 PY
