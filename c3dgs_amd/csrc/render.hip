@@ -26,20 +26,34 @@ namespace c3dgs {
 
 constexpr int BATCH = 256;
 
+// The staged LDS records carry the conic PRE-SCALED for the blend loops: {-0.5 a, -b, -0.5 c} x log2(e), so that the
+// exponent of  G = exp(-0.5 (a dx^2 + c dy^2) - b dx dy)  is three multiplies and three multiply-adds feeding v_exp_f32
+// (= 2^x) directly: two vector instructions per (pixel, Gaussian) pair fewer than the reference's form + exp (which is
+// exp2 of a product with log2(e) on this hardware anyway). Done once per staged entry, after the culling mask, which
+// works on the true conic.
+__device__ __forceinline__ void prescale_conic(float4& a, float4& b)
+{
+    constexpr float LOG2E = 1.4426950408889634f;
+    a.z *= -0.5f * LOG2E;
+    a.w *= -LOG2E;
+    b.x *= -0.5f * LOG2E;
+}
+
 // alpha of one Gaussian at one pixel; the SAME instruction sequence in forward and backward so both
 // take identical skip decisions (explicit fma placement, independent of -ffp-contract).
+// (ka, kb, kc) = the pre-scaled conic of prescale_conic().
 // returns false when the reference `continue`s (forward.cu:344-354 / backward.cu:494-501).
-__device__ __forceinline__ bool gaussian_alpha(float mx, float my, float ca, float cb, float cc, float op,
+__device__ __forceinline__ bool gaussian_alpha(float mx, float my, float ka, float kb, float kc, float op,
                                                float pxf, float pyf, float& dx, float& dy, float& G, float& alpha)
 {
     dx = mx - pxf;
     dy = my - pyf;
-    const float power = fmaf(-0.5f, fmaf(ca, dx * dx, cc * (dy * dy)), -(cb * (dx * dy)));
+    const float power2 = fmaf(kb, dx * dy, fmaf(kc, dy * dy, ka * (dx * dx)));     // = power * log2(e)
     // no early return: G and alpha are always written (callers select on the result anyway), which saves the compiler
     // a select per call; for power > 0 they hold values nobody uses
-    G = __expf(power);
+    G = __builtin_amdgcn_exp2f(power2);
     alpha = fminf(0.99f, op * G);
-    return !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+    return !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
 }
 
 // Which of the tile's four 8x8 quadrants (= waves) can this Gaussian touch at all?  A pixel only blends the
@@ -177,8 +191,9 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     }
     for (int r = 0; r < rounds; r++) {
         const int buf = r & 1;
-        s_ab[buf][tid][0] = ra; s_ab[buf][tid][1] = rb; s_c[buf][tid] = rc.x;
         const uint32_t qm = (r * BATCH + tid < n) ? quadrant_mask(ra, rb, tile_x0, tile_y0) : 0u;
+        prescale_conic(ra, rb);
+        s_ab[buf][tid][0] = ra; s_ab[buf][tid][1] = rb; s_c[buf][tid] = rc.x;
         if (r * BATCH + tid < n) qmask[range.x + r * BATCH + tid] = (uint8_t)qm;   // the backward reuses it (same test, ~100 VALU ops)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -433,7 +448,9 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
         uint32_t qm = 0u;
         if (mypos >= 0) {
             const uint32_t id = point_list[range.x + mypos];
-            const float4 a = splat[3 * (size_t)id], b = splat[3 * (size_t)id + 1], c = splat[3 * (size_t)id + 2];
+            float4 a = splat[3 * (size_t)id], b = splat[3 * (size_t)id + 1];
+            const float4 c = splat[3 * (size_t)id + 2];
+            prescale_conic(a, b);
             const uint32_t off = __float_as_uint(c.y), lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
             const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
             s_slot[tid] = block_base[id >> 8] + off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import oracle as orc_mod
-from tests import cases, gpu_util, synth
+from tests import cases, fullsize, gpu_util, synth
 from tests.test_raster_gpu import GRAD_TOL, _check_forward
 
 pytestmark = pytest.mark.gpu
@@ -72,17 +72,9 @@ def test_random_case_forward_and_backward(hip, orc, seed):
     dL = synth.grad_image(cam["W"], cam["H"], seed=seed).numpy()
     ref = orc.rasterize_backward(st, dL)
     got = gpu_util.hip_backward(fw, dL)
-    for k, v in got.items():
-        r_ = ref[k]
-        if r_.size == 0 and v.size == 0:
-            continue
-        if v.shape != r_.shape:
-            assert r_.size == 0 and not np.any(v), f"{what}: {k}"
-            continue
-        assert np.isfinite(v).all(), f"{what}: {k}"
-        err = gpu_util.rel_inf(v, r_)
-        # the 1e-4 bar holds for blend lists up to about a thousand entries; both sides rebuild T by dividing out
-        # (1 - alpha) entry by entry in fp32 (backward.cu:505), so the error grows with the depth of the list: the large
-        # cases reach 4,500-9,700 entries per tile (screen-filling splats) and are held to 1e-3
-        tol = 1e-3 if seed >= 1000 else GRAD_TOL
-        assert err <= tol, f"{what}: {k} rel-inf error {err:.3e}"
+    # the 1e-4 bar holds for blend lists up to about a thousand entries; both sides rebuild T by dividing out
+    # (1 - alpha) entry by entry in fp32 (backward.cu:505), so the error grows with the depth of the list: the large
+    # cases reach 4,500-9,700 entries per tile (screen-filling splats) and are held to 1e-3. Blend decisions that flip on a
+    # rounding difference of exp() are handled as tests/fullsize.py: check_grads describes (in a 4,500-deep tile one
+    # flipped pixel moved dL_drotations to 1.1e-3 once).
+    fullsize.check_grads(st, gpu_util.unpack(fw), got, ref, 1e-3 if seed >= 1000 else GRAD_TOL, what)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests import cases, gpu_util, synth
+from tests import cases, fullsize, gpu_util, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -55,7 +55,12 @@ def _check_forward(hipo, st, borderline_ok=False):
         bad = np.abs(a - b) > 2e-5 + 1e-4 * np.abs(b)
         assert bad.mean() <= 1e-4 and np.abs(a - b).max() <= 4e-3, (bad.sum(), np.abs(a - b).max())
     else:
-        np.testing.assert_allclose(a, b, atol=2e-5, rtol=1e-4)
+        # every pixel tight -- except that any two exp() implementations disagree on a blend decision (alpha >= 1/255,
+        # T < 1e-4) now and then (tests/fullsize.py: 32 such pixels over 315 random scenes, the same count for two
+        # different roundings of the exponent): at most two pixels, each off by at most one borderline contribution
+        bad = np.abs(a - b) > 2e-5 + 1e-4 * np.abs(b)
+        assert bad.any(0).sum() <= max(2, int(2e-5 * a.shape[1] * a.shape[2])) and np.abs(a - b).max() <= 4e-3, \
+            (bad.sum(), np.abs(a - b).max())
     # per-pixel bookkeeping: identical except where an exp() ulp flips a threshold (expected: almost never)
     same = (hipo["n_contrib"] == st.n_contrib).mean()
     assert same >= 0.999, f"n_contrib agreement {same}"
@@ -63,7 +68,8 @@ def _check_forward(hipo, st, borderline_ok=False):
         dT = np.abs(hipo["final_T"] - st.final_T)
         assert (dT > 1e-5 + 1e-4 * np.abs(st.final_T)).mean() <= 1e-4 and dT.max() <= 4e-3
     else:
-        np.testing.assert_allclose(hipo["final_T"], st.final_T, atol=1e-5, rtol=1e-4)
+        dT = np.abs(hipo["final_T"] - st.final_T)
+        assert (dT > 1e-5 + 1e-4 * np.abs(st.final_T)).sum() <= max(2, int(2e-5 * dT.size)) and dT.max() <= 4e-3
 
 
 @pytest.mark.parametrize("name", cases.FORWARD_CASES)
@@ -82,16 +88,7 @@ def test_backward_parity(hip, orc, name):
     ref = orc.rasterize_backward(st, dL)
     fw = gpu_util.hip_forward(inp, cam, indexed)
     got = gpu_util.hip_backward(fw, dL)
-    for k, v in got.items():
-        r = ref[k]
-        if r.size == 0 and v.size == 0:
-            continue
-        if v.shape != r.shape:          # absent inputs: reference shape [P,..] zeros vs oracle's empty
-            assert r.size == 0 and not np.any(v), k
-            continue
-        assert np.isfinite(v).all(), k
-        err = gpu_util.rel_inf(v, r)
-        assert err <= GRAD_TOL, f"{name}:{k} rel-inf error {err:.3e}"
+    fullsize.check_grads(st, gpu_util.unpack(fw), got, ref, GRAD_TOL, name)
 
 
 def test_backward_is_deterministic(hip, orc):
