@@ -18,9 +18,10 @@ for tag in ("a", "b"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):
         k = r["Kernel_Name"]
-        for name in ("render_backward", "render_forward", "backward_preprocess", "preprocess_kernel", "os_pass_kernel"):
-            if name in k:
+        for name in ("render_backward", "render_forward", "sum_partials", "backward_preprocess", "preprocess_kernel", "os_pass_kernel"):
+            if name in k:                      # first match only: "preprocess_kernel" is a substring of the backward kernel's name
                 acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                break
     for name, d in acc.items():
         print(tag, name, {c: round(sum(v) / len(v)) for c, v in d.items()})
 PY

@@ -10,7 +10,8 @@ import json
 import re
 import sys
 
-STAGE = [("mark_visible", "mark_visible"), ("backward_preprocess", "backward_preprocess"), ("preprocess_kernel", "preprocess"),
+STAGE = [("mark_visible", "mark_visible"), ("sum_partials", "sum_partials"), ("backward_prep_kernel", "backward_prep"),
+         ("backward_preprocess", "backward_preprocess"), ("preprocess_kernel", "preprocess"),
          ("duplicate_with_keys", "duplicate_with_keys"), ("stamp_slots", "duplicate_with_keys"),
          ("identify_ranges", "identify_ranges"), ("render_forward", "render_forward"), ("render_backward", "render_backward"),
          ("wd_mfma", "weighted_distance"), ("weighted_distance_kernel", "weighted_distance")]
