@@ -44,10 +44,10 @@ struct BwdArgs {
     c3dgs_raster_grads g;
 };
 
-// SH backward. c = this Gaussian's coefficients; dst = gradient row (direct store or atomic scatter).
-template <int DEG, bool ATOMIC>
-__device__ __forceinline__ void sh_backward(const float* c, float* dst, int M, const f3 d0, const float g[3], float dmean_add[3],
-                                            float* basis_out)
+// SH backward. c = this Gaussian's coefficients; the gradient row is basis_out[k] * g[ch], which the caller writes (or
+// scatter-adds) cooperatively, a wave per row.
+template <int DEG>
+__device__ __forceinline__ void sh_backward(const float* c, const f3 d0, const float g[3], float dmean_add[3], float* basis_out)
 {
     const float len = sqrtf(d0.x * d0.x + d0.y * d0.y + d0.z * d0.z);
     const float x = d0.x / len, y = d0.y / len, z = d0.z / len;
@@ -98,16 +98,8 @@ __device__ __forceinline__ void sh_backward(const float* c, float* dst, int M, c
             }
         }
     }
-    if (ATOMIC) {                          // indexed: the caller scatter-adds cooperatively (see kernel)
 #pragma unroll
-        for (int k = 0; k < NB; k++) basis_out[k] = basis[k];
-    } else if (dst) {
-#pragma unroll
-        for (int k = 0; k < NB; k++)
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) dst[k * 3 + ch] = basis[k] * g[ch];
-        for (int k = NB * 3; k < M * 3; k++) dst[k] = 0.f;   // coefficients above the active degree
-    }
+    for (int k = 0; k < NB; k++) basis_out[k] = basis[k];
     const float ddx = dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2];
     const float ddy = dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2];
     const float ddz = dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2];
@@ -244,6 +236,26 @@ __global__ void __launch_bounds__(64 * C3DGS_SUM_WAVES) sum_partials_kernel(cons
     // majority on dense scenes) has exactly zero gradients: zero rows here, no SH / codebook gathers, no scatter-adds.
     // Same values as the reference, which adds nothing for it. (any_written implies i < P and radii[i] > 0.)
     const bool live = any_written;
+    const unsigned long long lm = __ballot(live);
+    const bool per_gaussian_rows = !a.sh_indices && !a.g_indices;          // non-indexed: [P, M, 3] SH gradient
+    // Zero SH rows of the non-indexed variant (192 B per Gaussian at M = 16: the bulk of this kernel's stores on a dense view):
+    // the wave's 64 rows are one contiguous span, cleared with coalesced 16-byte stores that skip the blended Gaussians'
+    // rows (a lane zeroing its own row wrote 48 dwords at a 192-byte stride: 0.41 ms for this kernel at P = 3M, 0.12 indexed).
+    bool sh_rows_done = false;
+    if (per_gaussian_rows && o.dL_dsh && a.sh && ((a.M * 3) & 3) == 0 && (reinterpret_cast<uintptr_t>(o.dL_dsh) & 15u) == 0) {
+        sh_rows_done = true;
+        const int r4 = (a.M * 3) >> 2;                                     // 16-byte words per row
+        const int first = blockIdx.x * LIST + wv * 64;                     // the wave's first Gaussian
+        const int rows = min(64, a.P - first);
+        float4* span = reinterpret_cast<float4*>(o.dL_dsh + (size_t)first * a.M * 3);
+        int row = lane_ / r4, col = lane_ - row * r4;                      // 16-byte word q = row * r4 + col, walked with stride 64
+        const int drow = 64 / r4, dcol = 64 - drow * r4;
+        for (int q = lane_; q < rows * r4; q += 64) {
+            if (!((lm >> row) & 1ull)) span[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            row += drow; col += dcol;
+            if (col >= r4) { col -= r4; row++; }
+        }
+    }
     if (i < a.P && !live) {
         if (o.dL_dmeans2D) { o.dL_dmeans2D[3 * si] = 0.f; o.dL_dmeans2D[3 * si + 1] = 0.f; o.dL_dmeans2D[3 * si + 2] = 0.f; }
         if (o.dL_dcolors) { o.dL_dcolors[3 * si] = 0.f; o.dL_dcolors[3 * si + 1] = 0.f; o.dL_dcolors[3 * si + 2] = 0.f; }
@@ -251,8 +263,8 @@ __global__ void __launch_bounds__(64 * C3DGS_SUM_WAVES) sum_partials_kernel(cons
         if (o.dL_dmeans3D) { o.dL_dmeans3D[3 * si] = 0.f; o.dL_dmeans3D[3 * si + 1] = 0.f; o.dL_dmeans3D[3 * si + 2] = 0.f; }
         if (o.dL_dcov3D) for (int q = 0; q < 6; q++) o.dL_dcov3D[6 * si + q] = 0.f;
         if (o.dL_dscale_factors) o.dL_dscale_factors[si] = 0.f;
-        if (!a.sh_indices && !a.g_indices) {                  // non-indexed: per-Gaussian rows
-            if (o.dL_dsh && a.sh) for (int q = 0; q < a.M * 3; q++) o.dL_dsh[si * a.M * 3 + q] = 0.f;
+        if (per_gaussian_rows) {
+            if (o.dL_dsh && a.sh && !sh_rows_done) for (int q = 0; q < a.M * 3; q++) o.dL_dsh[si * a.M * 3 + q] = 0.f;
             if (o.dL_dscales && a.scales) for (int q = 0; q < 3; q++) o.dL_dscales[3 * si + q] = 0.f;
             if (o.dL_drotations && a.scales) for (int q = 0; q < 4; q++) o.dL_drotations[4 * si + q] = 0.f;
         }
@@ -261,7 +273,6 @@ __global__ void __launch_bounds__(64 * C3DGS_SUM_WAVES) sum_partials_kernel(cons
     // global list would cost one same-address atomic per wave). The nine sums are parked in the Gaussian's own FIRST slot
     // of the partial-sum array (only this wave reads this wave's slots, and it is done with them).
     __shared__ uint32_t s_cnt[SW];
-    const unsigned long long lm = __ballot(live);
     if (lane_ == 0) s_cnt[wv] = (uint32_t)__popcll(lm);
     __syncthreads();
     uint32_t run0 = 0, all = 0;
@@ -311,14 +322,16 @@ backward_preprocess_kernel(const BwdArgs a, const float* __restrict__ cam_view, 
     // (MI355X_MICROARCH.md, Global float atomics: ~17x below the contiguous rate). Instead every lane parks its
     // factors in LDS and the wave then walks its 64 Gaussians together: one atomic instruction per Gaussian whose
     // lanes cover that Gaussian's contiguous gradient row (up to 48 floats = 192 B for SH).
-    __shared__ float s_g[INDEXED ? 256 : 1][3];
-    __shared__ int32_t s_row[INDEXED ? 256 : 1];      // codebook rows fit int32 (SHS, GS are int32 in the ABI)
+    // (The non-indexed variant writes its [P, M, 3] rows the same cooperative way, with plain stores.)
+    __shared__ float s_g[256][3];
+    __shared__ int32_t s_row[256];                    // codebook rows fit int32 (SHS, GS are int32 in the ABI), so do Gaussian ids
     __shared__ float s_ds[INDEXED ? 256 : 1][3];
     __shared__ float s_dq[INDEXED ? 256 : 1][4];
     __shared__ int32_t s_gi[INDEXED ? 256 : 1];
-    __shared__ float s_bas[INDEXED ? 256 : 1][NB + 1];  // SH basis values of the workgroup's Gaussians
+    __shared__ float s_bas[256][NB + 1];              // SH basis values of the workgroup's Gaussians
 #define s_basis(t, k) s_bas[t][k]
-    if (INDEXED) { s_row[threadIdx.x] = -1; s_gi[threadIdx.x] = -1; }
+    s_row[threadIdx.x] = -1;
+    if (INDEXED) s_gi[threadIdx.x] = -1;
 
     if (live) {
     // Memory round trips are what this kernel's time is made of (random rows, four waves per SIMD), so the loads are
@@ -375,10 +388,9 @@ backward_preprocess_kernel(const BwdArgs a, const float* __restrict__ cam_view, 
     if (a.sh) {
         const float g[3] = { (cl & 1) ? 0.f : acc[0], (cl & 2) ? 0.f : acc[1], (cl & 4) ? 0.f : acc[2] };
         const f3 d0 = { m.x - cam_pos[0], m.y - cam_pos[1], m.z - cam_pos[2] };
-        float* dst = o.dL_dsh ? o.dL_dsh + row * (size_t)a.M * 3 : nullptr;
         float basis[NB];
-        sh_backward<DEG, INDEXED>(c, dst, a.M, d0, g, sh_add, basis);
-        if (INDEXED && o.dL_dsh) {
+        sh_backward<DEG>(c, d0, g, sh_add, basis);                       // the row itself is written cooperatively below
+        if (o.dL_dsh) {
 #pragma unroll
             for (int k = 0; k < NB; k++) s_basis(threadIdx.x, k) = basis[k];
             s_g[threadIdx.x][0] = g[0]; s_g[threadIdx.x][1] = g[1]; s_g[threadIdx.x][2] = g[2];
@@ -521,21 +533,27 @@ backward_preprocess_kernel(const BwdArgs a, const float* __restrict__ cam_view, 
     }
     } // live
 
-    if (INDEXED) {
-        // each wave scatter-adds its own 64 rows: wave-level ordering of the LDS traffic is all that is needed
+    {
+        // each wave scatter-adds (indexed) or stores (non-indexed) its own 64 rows: wave-level ordering of the LDS traffic is
+        // all that is needed
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
         if (o.dL_dsh && a.sh) {
-            const int k = lane / 3, ch = lane - 3 * k;
+            const int k = min(lane / 3, NB - 1), ch = lane - 3 * (lane / 3);
             for (int j = 0; j < 64; j++) {
                 const int32_t row = s_row[wbase + j];            // wave-uniform
                 if (row < 0) continue;
-                if (lane < NB * 3)
-                    atomicAdd(o.dL_dsh + (size_t)row * a.M * 3 + lane, s_basis(wbase + j, k) * s_g[wbase + j][ch]);
+                float* dst = o.dL_dsh + (size_t)row * a.M * 3 + lane;
+                const float v = s_basis(wbase + j, k) * s_g[wbase + j][ch];
+                if (INDEXED) { if (lane < NB * 3) atomicAdd(dst, v); }
+                else if (lane < a.M * 3) *dst = lane < NB * 3 ? v : 0.f;   // coefficients above the active degree: zero
             }
         }
+    }
+    if (INDEXED) {
+        const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
         if (a.scales) {
             if (o.dL_dscales)
 #pragma unroll
