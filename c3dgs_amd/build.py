@@ -27,7 +27,8 @@ SOURCES = {
     "radix_sort.hip": os.environ.get("C3DGS_SORT_FLAGS", "").split(),
     # SLP packing into v_pk_*_f32 costs register shuffles in the blend loops and keeps DPP adds from fusing
     "render.hip": os.environ.get("C3DGS_RENDER_FLAGS", "-fno-slp-vectorize").split(),
-    "vq.hip": [],
+    # MFMA accumulators in VGPRs (no v_accvgpr_read per value in the top-2 update of the search kernel)
+    "vq.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"] + os.environ.get("C3DGS_VQ_FLAGS", "").split(),
     "draws.hip": [],
     "loss.hip": [],
     "encode.hip": [],

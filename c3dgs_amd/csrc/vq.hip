@@ -147,7 +147,12 @@ __device__ __forceinline__ void top2_update(float v, uint32_t code, uint32_t kee
 {
     const float vp = __uint_as_float((__float_as_uint(v) & keep_mask) | code);
     second = __builtin_amdgcn_fmed3f(vp, best, second);
-    best = fminf(vp, best);
+    // a bare v_min_f32 (NaN operand -> the other one, as fminf): fminf() itself costs a canonicalising v_max per operand
+    // in IEEE mode, which made the update 5 instructions instead of 3 together with the accumulator read-back that
+    // -amdgpu-mfma-vgpr-form removes (c3dgs_amd/build.py)
+    float nb;
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(nb) : "v"(vp), "v"(best));
+    best = nb;
 }
 
 // SPLIT = false: the 4 waves of a workgroup own 64 points each and every wave scans the whole codebook tile.
@@ -660,7 +665,8 @@ void launch_vq_accumulate(int64_t B, int K, int D, const float* x, const float* 
         vq_accumulate_kernel<<<grid, 256, 0, s>>>(B, D, idx_bits, x, w, gather, idx, S);
     }
     if (dist && dist_sum) {
-        const unsigned g2 = (unsigned)std::min<int64_t>((B + 255) / 256, 1024);
+        // few workgroups: each ends with one double atomic on the same word (1024 of them were most of this kernel's 14 us)
+        const unsigned g2 = (unsigned)std::min<int64_t>((B + 4095) / 4096, 64);
         vq_dist_sum_kernel<<<g2, 256, 0, s>>>(B, dist, dist_sum);
     }
 }
@@ -689,11 +695,29 @@ vq_apply_kernel(int K, int D, const float* __restrict__ S, float* __restrict__ c
     }
 }
 
+// the same update with one thread per codebook ELEMENT (no trace normalisation): a row per thread runs D correctly rounded
+// divisions in sequence on 16 workgroups (16 us for K = 4096, D = 48: latency, not work)
+__global__ void __launch_bounds__(256)
+vq_apply_elem_kernel(int K, int D, const float* __restrict__ S, float* __restrict__ codebook, float* __restrict__ entry_importance,
+                     float decay, float alpha, float eps)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= K * D) return;
+    const int k = e / D, d = e - k * D;
+    const float aw = S[(size_t)k * (D + 1) + D];
+    if (d == 0) entry_importance[k] = __fadd_rn(__fmul_rn(entry_importance[k], decay), __fmul_rn(alpha, aw));
+    const float nw = __fdiv_rn(S[(size_t)k * (D + 1) + d], __fadd_rn(aw, eps));
+    codebook[e] = __fadd_rn(__fmul_rn(codebook[e], decay), __fmul_rn(alpha, nw));
+}
+
 void launch_vq_apply(int K, int D, const float* S, float* codebook, float* entry_importance, float decay, float alpha,
                      float eps, int scale_normalize, hipStream_t s)
 {
     if (K <= 0) return;
-    vq_apply_kernel<<<(K + 255) / 256, 256, 0, s>>>(K, D, S, codebook, entry_importance, decay, alpha, eps, scale_normalize);
+    if (!(scale_normalize && D >= 6) && (int64_t)K * D < ((int64_t)1 << 31))
+        vq_apply_elem_kernel<<<(unsigned)(((int64_t)K * D + 255) / 256), 256, 0, s>>>(K, D, S, codebook, entry_importance, decay, alpha, eps);
+    else
+        vq_apply_kernel<<<(K + 255) / 256, 256, 0, s>>>(K, D, S, codebook, entry_importance, decay, alpha, eps, scale_normalize);
 }
 
 } // namespace c3dgs
