@@ -85,10 +85,13 @@ PROTOTYPES = {
                                           C.c_void_p, C.c_void_p]),
     "c3dgs_vq_accumulate": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c3dgs_weighted_distance_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "c3dgs_weighted_distance_ws": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                             C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+                                             C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "c3dgs_debug_wd_scores": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c3dgs_vq_sums": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "c3dgs_vq_apply": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_int32, C.c_void_p]),
     "c3dgs_mt19937_fill": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.c_int64]),

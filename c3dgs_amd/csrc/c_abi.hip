@@ -448,16 +448,17 @@ int c3dgs_weighted_distance(int64_t N, int32_t C, int32_t K, const float* coefs,
     return C3DGS_OK;
 }
 
+size_t c3dgs_weighted_distance_ws_bytes(int64_t N, int32_t C, int32_t K) { return wd_ws_bytes(N, C, K); }
+
 int c3dgs_weighted_distance_ws(int64_t N, int32_t C, int32_t K, const float* coefs, const int64_t* gather, const float* codebook,
-                               float* out_dist, int64_t* out_idx, int32_t* flag_ws, int32_t flag_cap, void* stream)
+                               float* out_dist, int64_t* out_idx, void* ws, size_t ws_bytes, void* stream)
 {
     if (N < 0 || C < 0 || K <= 0) return fail(C3DGS_E_INVALID, "coefs and codebook must have same number of channels");
     if (N == 0) return C3DGS_OK;
     if (!coefs || !codebook || !out_dist || !out_idx) return fail(C3DGS_E_INVALID, "ceofs and codebook must have dimension 2");
     {
         StageTimer t_(ST_WDIST, (hipStream_t)stream);
-        if (launch_weighted_distance(N, C, K, coefs, gather, codebook, out_dist, out_idx, (hipStream_t)stream, flag_ws,
-                                     flag_ws ? flag_cap : 0))
+        if (launch_weighted_distance(N, C, K, coefs, gather, codebook, out_dist, out_idx, (hipStream_t)stream, ws, ws ? ws_bytes : 0))
             return fail(C3DGS_E_INVALID, "unsupported channel count");
     }
     C3DGS_STAGE("weighted_distance", 0, (hipStream_t)stream);
@@ -476,8 +477,8 @@ int c3dgs_vq_accumulate(int64_t B, int32_t K, int32_t D, const float* x, const f
 }
 
 int c3dgs_vq_sums(int64_t B, int32_t K, int32_t D, const float* x, const float* w, const int64_t* gather,
-                  const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, int32_t* flag_ws,
-                  int32_t flag_cap, void* stream)
+                  const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, void* ws, size_t ws_bytes,
+                  void* stream)
 {
     if (B < 0 || K <= 0 || D <= 0) return fail(C3DGS_E_INVALID, "bad sizes");
     if (!S || !dist_sum) return fail(C3DGS_E_INVALID, "S and dist_sum are required");
@@ -487,11 +488,20 @@ int c3dgs_vq_sums(int64_t B, int32_t K, int32_t D, const float* x, const float* 
     if (!x || !w || !codebook || !dist || !idx) return fail(C3DGS_E_INVALID, "x, w, codebook, dist and idx are required");
     {
         StageTimer t_(ST_WDIST, (hipStream_t)stream);
-        if (launch_weighted_distance(B, K, D, x, gather, codebook, dist, idx, (hipStream_t)stream, flag_ws, flag_ws ? flag_cap : 0))
+        if (launch_weighted_distance(B, K, D, x, gather, codebook, dist, idx, (hipStream_t)stream, ws, ws ? ws_bytes : 0))
             return fail(C3DGS_E_INVALID, "unsupported channel count");
     }
     C3DGS_STAGE("weighted_distance", 0, (hipStream_t)stream);
     return c3dgs_vq_accumulate(B, K, D, x, w, gather, idx, dist, S, dist_sum, stream);
+}
+
+int c3dgs_debug_wd_scores(int64_t N, int32_t C, int32_t K, const float* coefs, const float* codebook, float* scores, void* ws,
+                          size_t ws_bytes, float* out_dist, int64_t* out_idx, void* stream)
+{
+    if (!coefs || !codebook || !scores || !out_dist || !out_idx) return fail(C3DGS_E_INVALID, "debug_wd_scores: bad arguments");
+    if (launch_wd_debug_scores(N, C, K, coefs, codebook, scores, ws, ws_bytes, out_dist, out_idx, (hipStream_t)stream))
+        return fail(C3DGS_E_INVALID, "debug_wd_scores: K = 48, 1 <= N <= 256, C >= 32 and scratch of c3dgs_weighted_distance_ws_bytes");
+    return C3DGS_OK;
 }
 
 int c3dgs_vq_apply(int32_t K, int32_t D, const float* S, float* codebook, float* entry_importance, float decay,

@@ -178,7 +178,10 @@ void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* rad
                                 uint32_t* live_slots, const c3dgs_raster_grads& gr, hipStream_t s);
 // vq.hip
 int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const int64_t* gather, const float* codebook,
-                             float* out_dist, int64_t* out_idx, hipStream_t s, int* flag_list = nullptr, int flag_cap = 0);
+                             float* out_dist, int64_t* out_idx, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0);
+size_t wd_ws_bytes(int64_t N, int C, int K);
+int launch_wd_debug_scores(int64_t N, int C, int K, const float* coefs, const float* codebook, float* scores, void* ws, size_t ws_bytes,
+                           float* out_dist, int64_t* out_idx, hipStream_t s);
 void launch_vq_accumulate(int64_t B, int K, int D, const float* x, const float* w, const int64_t* gather,
                           const int64_t* idx, const float* dist, float* S, double* dist_sum, hipStream_t s);
 void launch_vq_apply(int K, int D, const float* S, float* codebook, float* entry_importance, float decay, float alpha,

@@ -317,6 +317,248 @@ wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
     }
 }
 
+// ---------------------------------------------------------------- the same search on the bf16 matrix cores (split operands)
+//
+// v_mfma_f32_32x32x16_bf16 runs 16x the multiply-adds per cycle of the fp32 form. An fp32 value is the exact sum of
+// three bf16 pieces  v = h + l + t  (h = bf16(v), l = bf16(v - h), t = bf16(v - h - l): 3 x 8 significant bits, same
+// exponent range as fp32), so a product x c is reproduced to ~2^-22 relative by the six piece products
+//     xh ch + xh cl + xl ch + xl cl + xh ct + xt ch        (dropped: xl ct, xt cl, xt ct and the split residuals)
+// each of which is EXACT in the fp32 accumulator's product stage (8 x 8 bits). Six bf16 MFMAs replace eight fp32 ones
+// per 16 dimensions: 18 x 32 cycles instead of 24 x 64 per 32 x 32 distances at K = 48. The search was never the exact
+// part of this path -- the winner's distance is recomputed with the reference's k-ordered chain and every point whose two
+// best candidates lie within the error margin is re-scanned exactly -- so only the margin has to cover the approximation:
+// the dropped terms (<= 2.4e-7 sum|x_k c_k|), the accumulation inside and between the 18 MFMAs (measured through
+// c3dgs_debug_wd_scores, tests/test_vq_gpu.py) and the 16-ulp row packing of top2_update.
+// The codebook is split ONCE per call by wd_split_codebook_kernel into MFMA A-operand fragments
+//     frag[tile][sub-tile (32 codewords)][k-step (16 dims)][piece][lane][8 x bf16]    (lane l: codeword l & 31, dims 8 (l >> 5) ..+7)
+// so staging a tile is a plain 16-byte copy and a wave's operand read is one conflict-free ds_read_b128.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BF_PIECES = 3;
+template <int MF_K> struct BfShape {
+    static constexpr int KS = (MF_K + 15) / 16;                                  // k-steps of 16 dims (zero-padded)
+    static constexpr int SUB_BYTES = KS * BF_PIECES * 64 * 16;                   // one 32-codeword sub-tile
+    static constexpr int TILE_BYTES = (MF_CT / 32) * SUB_BYTES;                  // 36,864 B at K = 48
+};
+
+__device__ __forceinline__ void bf16_split3(float v, __bf16& h, __bf16& l, __bf16& t)
+{
+    h = (__bf16)v;
+    const float r1 = v - (float)h;          // exact
+    l = (__bf16)r1;
+    const float r2 = r1 - (float)l;         // exact
+    t = (__bf16)r2;
+}
+
+size_t wd_split_bytes(int C, int K)
+{
+    const int ks = (K + 15) / 16;
+    const size_t ntiles = ((size_t)C + MF_CT - 1) / MF_CT;
+    return ntiles * (size_t)(MF_CT / 32) * ks * BF_PIECES * 64 * 16 + ntiles * MF_CT * sizeof(float);
+}
+
+// one thread per (tile, sub-tile, k-step, lane): 8 dims of one codeword -> its three 16-byte fragments;
+// the first C threads also compute ||c||^2 (k-ordered FMA chain, as the fp32 kernel does per tile)
+template <int MF_K>
+__global__ void __launch_bounds__(256)
+wd_split_codebook_kernel(int C, const float* __restrict__ codebook, uint4* __restrict__ frag, float* __restrict__ norms)
+{
+    constexpr int KS = BfShape<MF_K>::KS;
+    const int ntiles = (C + MF_CT - 1) / MF_CT;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < ntiles * MF_CT) {
+        float nr = 3.0e38f;                                  // rows past C never win
+        if (t < C) {
+            nr = 0.f;
+#pragma unroll
+            for (int k = 0; k < MF_K; k++) nr = fmaf(codebook[(size_t)t * MF_K + k], codebook[(size_t)t * MF_K + k], nr);
+        }
+        norms[t] = nr;
+    }
+    if (t >= ntiles * (MF_CT / 32) * KS * 64) return;
+    const int lane = t & 63, q = (t >> 6) % KS, ts = (t >> 6) / KS;      // ts = tile * 4 + sub
+    const int cw = ts * 32 + (lane & 31), k0 = 16 * q + 8 * (lane >> 5);
+    union { bf16x8 v; uint4 u; } p[BF_PIECES];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float v = (cw < C && k0 + j < MF_K) ? codebook[(size_t)cw * MF_K + k0 + j] : 0.f;
+        __bf16 h, l, tt;
+        bf16_split3(v, h, l, tt);
+        p[0].v[j] = h; p[1].v[j] = l; p[2].v[j] = tt;
+    }
+#pragma unroll
+    for (int e = 0; e < BF_PIECES; e++) frag[((size_t)(ts * KS + q) * BF_PIECES + e) * 64 + lane] = p[e].u;
+}
+
+// SCORES != nullptr (diagnostics, one workgroup's worth of points): also dumps s[n][c] = ||c||^2 - 2 x_n.c as the matrix cores
+// produced it, so a test can measure the approximation error the margin has to cover.
+template <int MF_K, bool SPLIT, bool SCORES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 74 KB of LDS: two workgroups per CU
+wd_bf16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather,
+               const float* __restrict__ codebook, const uint4* __restrict__ frag, const float* __restrict__ norms,
+               float* __restrict__ out_dist, int64_t* __restrict__ out_idx, int* __restrict__ flag_list, int flag_cap,
+               float margin_rel, float* __restrict__ scores)
+{
+    constexpr int KS = BfShape<MF_K>::KS;
+    constexpr int TILE_V = BfShape<MF_K>::TILE_BYTES / 16, SUB_V = BfShape<MF_K>::SUB_BYTES / 16;
+    constexpr int STAGE_PER_THREAD = (TILE_V + 255) / 256;
+    __shared__ uint4 s_frag[2][TILE_V];
+    __shared__ float s_norm[2][MF_CT];
+    __shared__ float s_mb[SPLIT ? 4 : 1][2][32], s_ms[SPLIT ? 4 : 1][2][32];
+    __shared__ int s_mi[SPLIT ? 4 : 1][2][32];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t n_base = SPLIT ? (int64_t)blockIdx.x * MF_PTS : ((int64_t)blockIdx.x * 4 + wave) * MF_PTS;
+
+    // B operands: the three pieces of -2 x[n_base + 32 g + i][16 q + 8 h + j], j = 0..7
+    bf16x8 bh[2][KS], bl[2][KS], bt[2][KS];
+    float xnorm[2];
+    int64_t rows[2];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const int64_t n = n_base + 32 * g + i;
+        const int64_t row = n < N ? (gather ? gather[n] : n) : 0;
+        rows[g] = row;
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < KS; q++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = 16 * q + 8 * h + j;
+                const float v = k < MF_K ? coefs[row * MF_K + k] : 0.f;
+                part = fmaf(v, v, part);
+                __bf16 ph, pl, pt;
+                bf16_split3(-2.0f * v, ph, pl, pt);
+                bh[g][q][j] = ph; bl[g][q][j] = pl; bt[g][q][j] = pt;
+            }
+        }
+        xnorm[g] = part + __shfl_xor(part, 32);
+    }
+    const float big = __uint_as_float(0x7f7ffff0u);
+    float best[2] = { big, big }, second[2] = { FLT_MAX, FLT_MAX };
+    int grp[2] = { 0, 0 };
+    const uint32_t keep_mask = 0xfffffff0u;
+
+    const int ntiles = (C + MF_CT - 1) / MF_CT;
+    static_assert(TILE_V % 256 == 0, "whole 16-byte vectors per thread");
+    uint4 st[STAGE_PER_THREAD];
+    float st_norm = 0.f;
+#define C3DGS_BF_STAGE_LOAD(tile_)                                                                                        \
+    {                                                                                                                     \
+        const uint4* src_ = frag + (size_t)(tile_) * TILE_V + tid;                                                        \
+        _Pragma("unroll") for (int e = 0; e < STAGE_PER_THREAD; e++) st[e] = src_[e * 256];                               \
+        if (tid < MF_CT) st_norm = norms[(size_t)(tile_) * MF_CT + tid];                                                  \
+    }
+#define C3DGS_BF_STAGE_STORE(buf_)                                                                                        \
+    {                                                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < STAGE_PER_THREAD; e++) s_frag[buf_][e * 256 + tid] = st[e];                 \
+        if (tid < MF_CT) s_norm[buf_][tid] = st_norm;                                                                     \
+    }
+    C3DGS_BF_STAGE_LOAD(0);
+    C3DGS_BF_STAGE_STORE(0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; tile++) {
+        const int buf = tile & 1;
+        C3DGS_BF_STAGE_LOAD(min(tile + 1, ntiles - 1));        // in flight behind this tile's MFMAs (last tile: re-read, unused)
+#pragma unroll 1
+        for (int sub = SPLIT ? wave : 0; sub < (SPLIT ? wave + 1 : MF_CT / 32); sub++) {
+            if (tile * MF_CT + sub * 32 >= C) break;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float nv = s_norm[buf][sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+                acc0[r] = nv; acc1[r] = nv;
+            }
+            const uint4* fsub = &s_frag[buf][sub * SUB_V + lane];
+#pragma unroll
+            for (int q = 0; q < KS; q++) {
+                union { uint4 u; bf16x8 v; } ah, al, at;
+                ah.u = fsub[(q * BF_PIECES + 0) * 64];
+                al.u = fsub[(q * BF_PIECES + 1) * 64];
+                at.u = fsub[(q * BF_PIECES + 2) * 64];
+                // smallest pieces first
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.v, bh[0][q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.v, bh[1][q], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bt[0][q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bt[1][q], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bl[0][q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bl[1][q], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh[0][q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh[1][q], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl[0][q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl[1][q], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh[0][q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh[1][q], acc1, 0, 0, 0);
+            }
+            if (SCORES) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int c = tile * MF_CT + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int64_t n0 = n_base + i, n1 = n_base + 32 + i;
+                    if (c < C && n0 < N) scores[n0 * C + c] = acc0[r];
+                    if (c < C && n1 < N) scores[n1 * C + c] = acc1[r];
+                }
+            }
+            const float was0 = best[0], was1 = best[1];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                top2_update(acc0[r], (uint32_t)r, keep_mask, best[0], second[0]);
+                top2_update(acc1[r], (uint32_t)r, keep_mask, best[1], second[1]);
+            }
+            const int gid = tile * (MF_CT / 32) + sub;
+            grp[0] = best[0] < was0 ? gid : grp[0];
+            grp[1] = best[1] < was1 ? gid : grp[1];
+        }
+        C3DGS_BF_STAGE_STORE(buf ^ 1);                         // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const int code = (int)(__float_as_uint(best[g]) & 15u);
+        const int my_idx = grp[g] * 32 + (code & 3) + 8 * (code >> 2) + 4 * h;
+        const float ob = __shfl_xor(best[g], 32), os = __shfl_xor(second[g], 32);
+        const int oi = __shfl_xor(my_idx, 32);
+        float nb = fminf(best[g], ob);
+        float ns = fminf(fminf(second[g], os), fmaxf(best[g], ob));
+        int ni = (ob < best[g] || (ob == best[g] && oi < my_idx)) ? oi : my_idx;
+        if (SPLIT) {
+            if (h == 0) { s_mb[wave][g][i] = nb; s_ms[wave][g][i] = ns; s_mi[wave][g][i] = ni; }
+            __syncthreads();
+            if (wave != 0) continue;
+            nb = s_mb[0][g][i]; ns = s_ms[0][g][i]; ni = s_mi[0][g][i];
+#pragma unroll
+            for (int w = 1; w < 4; w++) {
+                const float wb = s_mb[w][g][i], ws = s_ms[w][g][i];
+                const int wi = s_mi[w][g][i];
+                ns = fminf(fminf(ns, ws), fmaxf(nb, wb));
+                const bool take = wb < nb || (wb == nb && wi < ni);
+                nb = fminf(nb, wb);
+                ni = take ? wi : ni;
+            }
+        }
+        const int64_t n = n_base + 32 * g + i;
+        if (h == 0 && n < N) {
+            const float db = nb + xnorm[g], ds = ns + xnorm[g];
+            const float margin = margin_rel * (fabsf(db) + fabsf(ds) + 2.0f * xnorm[g]) + 1e-37f;
+            const bool ambiguous = !(ns - nb > margin);
+            const float* x = coefs + rows[g] * MF_K;
+            const float* cb = codebook + (size_t)ni * MF_K;
+            float r = 0.f;
+#pragma unroll
+            for (int k = 0; k < MF_K; k++) {
+                const float d = x[k] - cb[k];
+                r = fmaf(d, d, r);
+            }
+            out_dist[n] = r;
+            out_idx[n] = ambiguous ? (int64_t)-1 : (int64_t)ni;
+            if (ambiguous && flag_list) {
+                const int pos = atomicAdd(&flag_list[0], 1);
+                if (pos < flag_cap) flag_list[1 + pos] = (int)n;
+            }
+        }
+    }
+}
+
 // exact re-scan of the flagged points. A workgroup owns 64 consecutive points; for every flagged one its 256 threads
 // split the codewords (thread t takes t, t+256, ...: k-ordered FMA chain per codeword, strict '<' per thread keeps its
 // lowest index), then a wave + LDS argmin that prefers the lower index on ties (== the sequential strict '<').
@@ -448,29 +690,59 @@ wd_fixup_list_kernel(int C, const float* __restrict__ coefs, const int64_t* __re
     }
 }
 
+// margin of the split-bf16 search, relative to (d_best + d_second + 2 ||x||^2): measured worst error of a score
+// 1.2e-6 of that scale (tests/test_vq_gpu.py::test_bf16_scores_within_margin) + the 16-ulp row packing 1.9e-6 + the
+// exact chain's own rounding (the fp32 search's 4e-5 covered a 48-step chain on both sides with the same headroom)
+constexpr float WD_BF16_MARGIN = 4e-5f;
+
+// ws (optional device scratch, 16-byte aligned): [split codebook: wd_split_bytes(C, K)][int32 list of ambiguous points: 1 + cap].
+// With room for the split codebook the search runs on the bf16 matrix cores, otherwise on the fp32 ones; whatever is
+// left holds the list (without a list the flagged points are re-scanned one by one).
 template <int K>
 static void launch_wd_mfma(int64_t N, int C, const float* coefs, const int64_t* gather, const float* codebook, float* out_dist,
-                           int64_t* out_idx, int* flag_list, int flag_cap, hipStream_t s)
+                           int64_t* out_idx, void* ws, size_t ws_bytes, hipStream_t s)
 {
     const unsigned g1 = (unsigned)((N + 4 * MF_PTS - 1) / (4 * MF_PTS)), g2 = (unsigned)((N + 63) / 64);
     // fewer than one 4-wave workgroup per CU (256 CUs): let the 4 waves share 64 points and split the codebook instead
     // (measured, K = 4096 x 48: N = 32,768: 267 -> 158 us; N = 65,536: 271 vs 283 us, so the plain kernel from there on;
     // profiles/r02a_vq_slices.txt)
     static const int split_env = []() { const char* e = getenv("C3DGS_VQ_SPLIT"); return e ? atoi(e) : -1; }();   // A/B switch for tests
+    static const bool force_f32 = getenv("C3DGS_VQ_F32_MFMA") != nullptr;                                          // A/B switch
+    static const float margin_env = []() { const char* e = getenv("C3DGS_VQ_BF16_MARGIN"); return e ? (float)atof(e) : WD_BF16_MARGIN; }();
     const bool split = split_env >= 0 ? split_env != 0 : g1 < 256;
-    const bool listed = flag_list && flag_cap > 0 && N < ((int64_t)1 << 31);
+    const size_t sb = wd_split_bytes(C, K);
+    const bool bf16 = K >= 12 && ws && ws_bytes >= sb && (((uintptr_t)ws) & 15) == 0 && !force_f32;
+    char* rest = (char*)ws + (bf16 ? sb : 0);
+    const size_t rest_bytes = ws ? ws_bytes - (bf16 ? sb : 0) : 0;
+    int* flag_list = rest_bytes >= 2 * sizeof(int) && N < ((int64_t)1 << 31) ? (int*)rest : nullptr;
+    const int flag_cap = flag_list ? (int)std::min<size_t>(rest_bytes / sizeof(int) - 1, (size_t)0x7fffffff) : 0;
+    const bool listed = flag_list != nullptr;
     if (listed) (void)hipMemsetAsync(flag_list, 0, sizeof(int), s);
-    if (split) wd_mfma_kernel<K, true><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, listed ? flag_list : nullptr, listed ? flag_cap : 0);
-    else wd_mfma_kernel<K, false><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, listed ? flag_list : nullptr, listed ? flag_cap : 0);
+    if (bf16) {
+        uint4* frag = (uint4*)ws;
+        float* norms = (float*)((char*)ws + sb) - (size_t)((C + MF_CT - 1) / MF_CT) * MF_CT;
+        const int ntiles = (C + MF_CT - 1) / MF_CT;
+        const unsigned gs = (unsigned)((ntiles * (MF_CT / 32) * BfShape<K>::KS * 64 + 255) / 256);
+        wd_split_codebook_kernel<K><<<std::max(gs, (unsigned)((ntiles * MF_CT + 255) / 256)), 256, 0, s>>>(C, codebook, frag, norms);
+        if (split) wd_bf16_kernel<K, true, false><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, frag, norms, out_dist, out_idx, flag_list, flag_cap, margin_env, nullptr);
+        else wd_bf16_kernel<K, false, false><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, frag, norms, out_dist, out_idx, flag_list, flag_cap, margin_env, nullptr);
+    } else if (split) wd_mfma_kernel<K, true><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
+    else wd_mfma_kernel<K, false><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
     if (listed) {
-        const unsigned gl = (unsigned)std::min<int64_t>(1024, (flag_cap + WD_FB - 1) / WD_FB);
+        const unsigned gl = (unsigned)std::min<int64_t>(1024, ((int64_t)flag_cap + WD_FB - 1) / WD_FB);
         wd_fixup_list_kernel<K><<<gl, 256, 0, s>>>(C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
     }
     wd_fixup_kernel<K><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);   // whatever is still flagged
 }
 
+size_t wd_ws_bytes(int64_t N, int C, int K)
+{
+    const size_t list = ((size_t)(N > 0 ? N : 0) / 8 + 2) * sizeof(int);           // ~1-2 % of the points are ambiguous
+    return ((K == 48 || K == 12) ? wd_split_bytes(C, K) : 0) + list;
+}
+
 int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const int64_t* gather, const float* codebook,
-                             float* out_dist, int64_t* out_idx, hipStream_t s, int* flag_list, int flag_cap)
+                             float* out_dist, int64_t* out_idx, hipStream_t s, void* ws, size_t ws_bytes)
 {
     if (N <= 0) return 0;
     const int64_t per_block = (int64_t)WD_BLOCK * WD_PPT;
@@ -478,9 +750,9 @@ int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const 
     const bool al16 = (((uintptr_t)coefs | (uintptr_t)codebook) & 15) == 0;
     const bool al8 = (((uintptr_t)coefs | (uintptr_t)codebook) & 7) == 0;
     static const bool force_exact = getenv("C3DGS_VQ_EXACT_VALU") != nullptr;   // A/B switch for tests and profiling
-    if (K == 48 && al16 && C >= 32 && !force_exact) launch_wd_mfma<48>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap, s);
-    else if (K == 12 && al8 && C >= 32 && !force_exact) launch_wd_mfma<12>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap, s);
-    else if (K == 6 && al8 && C >= 32 && !force_exact) launch_wd_mfma<6>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap, s);
+    if (K == 48 && al16 && C >= 32 && !force_exact) launch_wd_mfma<48>(N, C, coefs, gather, codebook, out_dist, out_idx, ws, ws_bytes, s);
+    else if (K == 12 && al8 && C >= 32 && !force_exact) launch_wd_mfma<12>(N, C, coefs, gather, codebook, out_dist, out_idx, ws, ws_bytes, s);
+    else if (K == 6 && al8 && C >= 32 && !force_exact) launch_wd_mfma<6>(N, C, coefs, gather, codebook, out_dist, out_idx, ws, ws_bytes, s);
     else if (K == 48 && al16) weighted_distance_kernel<48, 128><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
     else if (K == 12 && al16) weighted_distance_kernel<12, 512><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
     else if (K == 6 && al8) weighted_distance_kernel<6, 1024><<<grid, WD_BLOCK, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
@@ -489,6 +761,21 @@ int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const 
         const unsigned g2 = (unsigned)((N + WD_BLOCK - 1) / WD_BLOCK);
         weighted_distance_generic_kernel<6144><<<g2, WD_BLOCK, 0, s>>>(N, C, K, coefs, gather, codebook, out_dist, out_idx);
     }
+    return 0;
+}
+
+// diagnostics: the scores s[n][c] = ||c||^2 - 2 x_n.c exactly as the split-bf16 search forms them (K = 48, N <= 256 points)
+int launch_wd_debug_scores(int64_t N, int C, int K, const float* coefs, const float* codebook, float* scores, void* ws, size_t ws_bytes,
+                           float* out_dist, int64_t* out_idx, hipStream_t s)
+{
+    if (K != 48 || N <= 0 || N > 256 || C < 32 || !ws || ws_bytes < wd_split_bytes(C, K) || (((uintptr_t)ws) & 15)) return 1;
+    const size_t sb = wd_split_bytes(C, K);
+    uint4* frag = (uint4*)ws;
+    const int ntiles = (C + MF_CT - 1) / MF_CT;
+    float* norms = (float*)((char*)ws + sb) - (size_t)ntiles * MF_CT;
+    const unsigned gs = (unsigned)((ntiles * (MF_CT / 32) * BfShape<48>::KS * 64 + 255) / 256);
+    wd_split_codebook_kernel<48><<<std::max(gs, (unsigned)((ntiles * MF_CT + 255) / 256)), 256, 0, s>>>(C, codebook, frag, norms);
+    wd_bf16_kernel<48, false, true><<<1, 256, 0, s>>>(N, C, coefs, nullptr, codebook, frag, norms, out_dist, out_idx, nullptr, 0, WD_BF16_MARGIN, scores);
     return 0;
 }
 

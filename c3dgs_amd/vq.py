@@ -49,10 +49,12 @@ def weightedDistance(coefs: torch.Tensor, codebook: torch.Tensor, gather: Option
     idx = torch.zeros(N, dtype=torch.int64, device=x.device)
     if N > 0 and cb.size(0) > 0:
         with torch.cuda.device(x.device):
-            flags = torch.empty(N // 8 + 2, dtype=torch.int32, device=x.device)     # list of ambiguous points (typically ~1 %)
+            # scratch: the codebook split into bf16 pieces for the matrix cores + the list of ambiguous points (~1 %)
+            ws = torch.empty(int(L.c3dgs_weighted_distance_ws_bytes(N, int(cb.size(0)), int(x.size(1)))), dtype=torch.uint8,
+                             device=x.device)
             rc = L.c3dgs_weighted_distance_ws(N, int(cb.size(0)), int(x.size(1)), x.data_ptr(),
                                               gather.data_ptr() if gather is not None else None, cb.data_ptr(),
-                                              dist.data_ptr(), idx.data_ptr(), flags.data_ptr(), int(flags.numel()) - 1,
+                                              dist.data_ptr(), idx.data_ptr(), ws.data_ptr(), int(ws.numel()),
                                               _stream(x.device))
         _lib.check(rc)
     return dist, idx
@@ -104,11 +106,12 @@ class HipOps:
         if bufs is None:
             bufs = (torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.int64, device=dev),
                     torch.empty(K, D + 1, dtype=torch.float32, device=dev),
-                    torch.empty(B // 8 + 2, dtype=torch.int32, device=dev))        # list of ambiguous points (typically ~1 %)
+                    # the assignment's scratch: split codebook + list of ambiguous points (typically ~1 %)
+                    torch.empty(int(L.c3dgs_weighted_distance_ws_bytes(B, K, D)), dtype=torch.uint8, device=dev))
             if scratch is not None:
                 scratch.clear()
                 scratch[key] = bufs
-        dist, idx, S, flags = bufs
+        dist, idx, S, ws = bufs
         dsum = torch.empty(1, dtype=torch.float64, device=dev) if dsum_out is None else dsum_out
         xw = x.detach().contiguous().float()
         w = importance.detach().contiguous().float()
@@ -118,7 +121,7 @@ class HipOps:
         with torch.cuda.device(dev):
             rc = L.c3dgs_vq_sums(B, K, D, xw.data_ptr(), w.data_ptr(), gather.data_ptr() if gather is not None else None,
                                  cb.data_ptr(), dist.data_ptr(), idx.data_ptr(), S.data_ptr(), dsum.data_ptr(),
-                                 flags.data_ptr(), int(flags.numel()) - 1, _stream(dev))
+                                 ws.data_ptr(), int(ws.numel()), _stream(dev))
         _lib.check(rc)
         return dist, S, dsum
 

@@ -138,11 +138,22 @@ int c3dgs_rasterize_gaussians_backward_indexed(const c3dgs_raster_params* p, con
 int c3dgs_weighted_distance(int64_t N, int32_t C, int32_t K, const float* coefs, const int64_t* gather,
                             const float* codebook, float* out_dist, int64_t* out_idx, void* stream);
 
-/* the same with device scratch (int32[flag_cap + 1]) for the list of ambiguous points, which are then re-scanned several
- * per codebook pass instead of one by one; identical results */
+/* the same with device scratch `ws` (16-byte aligned, c3dgs_weighted_distance_ws_bytes(N, C, K) bytes; less is legal):
+ *   [the codebook split into three bf16 pieces per value, laid out as matrix-core operand fragments][int32 list of the points
+ *    whose two best candidates the fast search cannot tell apart].
+ * With room for the split codebook (K = 48 or 12) the candidate search runs on the bf16 matrix cores with six piece products
+ * per multiply (16x the fp32 matrix rate per product, ~2^-22 relative error per term); without, on the fp32 matrix cores.
+ * Either way the winner's distance is recomputed with the reference's k-ordered chain and every point inside the error
+ * margin is re-scanned exactly (listed points several per codebook pass): identical results, distances and indices. */
+size_t c3dgs_weighted_distance_ws_bytes(int64_t N, int32_t C, int32_t K);
 int c3dgs_weighted_distance_ws(int64_t N, int32_t C, int32_t K, const float* coefs, const int64_t* gather,
-                               const float* codebook, float* out_dist, int64_t* out_idx, int32_t* flag_ws, int32_t flag_cap,
+                               const float* codebook, float* out_dist, int64_t* out_idx, void* ws, size_t ws_bytes,
                                void* stream);
+
+/* diagnostics for tests: scores[n * C + c] = ||c||^2 - 2 x_n.c as the split-bf16 search forms them (K = 48, N <= 256,
+ * C >= 32; ws as above), so the error the ambiguity margin must cover can be measured against float64. */
+int c3dgs_debug_wd_scores(int64_t N, int32_t C, int32_t K, const float* coefs, const float* codebook, float* scores, void* ws,
+                          size_t ws_bytes, float* out_dist, int64_t* out_idx, void* stream);
 
 /* ---- VectorQuantize.update, split at the point where a sharded run all-reduces (compression/vq.py:28-35) ----
  * accumulate: S[k, 0..D) += w_n * x_n ; S[k, D] += w_n for k = idx[n];  *dist_sum += sum_n dist[n] (may be NULL).
@@ -153,11 +164,11 @@ int c3dgs_vq_accumulate(int64_t B, int32_t K, int32_t D, const float* x, const f
 
 /* sums: the first half of a Lloyd step in ONE call -- clears S and *dist_sum, assigns the B (gathered) rows
  * (== c3dgs_weighted_distance into dist / idx) and accumulates them (== c3dgs_vq_accumulate).
- * flag_ws (optional, int32[flag_cap + 1] device scratch): lets the assignment list the points whose two best candidates
- * are too close to call from the fast search and re-scan them several per codebook pass; same results without it. */
+ * ws / ws_bytes (optional): the scratch of c3dgs_weighted_distance_ws (c3dgs_weighted_distance_ws_bytes(B, K, D)); same
+ * results without it. */
 int c3dgs_vq_sums(int64_t B, int32_t K, int32_t D, const float* x, const float* w, const int64_t* gather,
-                  const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, int32_t* flag_ws,
-                  int32_t flag_cap, void* stream);
+                  const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, void* ws, size_t ws_bytes,
+                  void* stream);
 
 /* apply: entry_importance = decay*entry_importance + alpha*S[:,D];
  *        codebook = decay*codebook + alpha * S[:, :D] / (S[:,D] + eps)        (ema_inplace, vq.py:45-46)

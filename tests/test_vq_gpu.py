@@ -228,6 +228,63 @@ def test_weighted_distance_nan_rows_fall_back_to_codeword_zero(hip):
     assert torch.equal(i[ok.cuda()], i2) and torch.equal(d[ok.cuda()], d2)
 
 
+def test_bf16_scores_within_margin(hip):
+    """The candidate search of K = 48 / 12 runs on the bf16 matrix cores with every operand split into three bf16 pieces and
+    six piece products per multiply (csrc/vq.hip). Its scores s[n][c] = ||c||^2 - 2 x_n.c only have to be accurate enough
+    for the ambiguity margin (4e-5 of d + 2||x||^2 per candidate pair) to be a valid bound: measure them against float64."""
+    import ctypes as C
+    from c3dgs_amd import _lib
+    L = _lib.lib()
+    worst = 0.0
+    for seed, scale, offset in [(0, 0.1, 0.0), (1, 1.0, 0.0), (2, 0.1, 0.5), (3, 10.0, 100.0), (4, 1e-3, 0.0), (5, 1.0, -3.0)]:
+        g = torch.Generator().manual_seed(seed)
+        N, Cn, K = 256, 1024 - 7 * seed, 48
+        x = (torch.randn(N, K, generator=g) * scale + offset).float().cuda()
+        cb = (torch.randn(Cn, K, generator=g) * scale * (1 + seed) + offset).float().cuda()
+        nb = int(L.c3dgs_weighted_distance_ws_bytes(N, Cn, K))
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        scores = torch.full((N, Cn), float("nan"), dtype=torch.float32, device="cuda")
+        dist = torch.empty(N, dtype=torch.float32, device="cuda")
+        idx = torch.empty(N, dtype=torch.int64, device="cuda")
+        rc = L.c3dgs_debug_wd_scores(N, Cn, K, x.data_ptr(), cb.data_ptr(), scores.data_ptr(), ws.data_ptr(), nb,
+                                     dist.data_ptr(), idx.data_ptr(), None)
+        _lib.check(rc)
+        torch.cuda.synchronize()
+        xd, cd = x.double().cpu(), cb.double().cpu()
+        exact = (cd ** 2).sum(-1)[None] - 2.0 * xd @ cd.T
+        d = ((xd[:, None] - cd[None]) ** 2).sum(-1)
+        rel = (scores.double().cpu() - exact).abs() / (d + 2.0 * (xd ** 2).sum(-1)[:, None])
+        assert torch.isfinite(rel).all()
+        worst = max(worst, float(rel.max()))
+    print(f"split-bf16 score error: {worst:.3e} of (d + 2||x||^2)")
+    assert worst < 5e-6, worst                                    # the margin is 4e-5 of (d_best + d_second + 2||x||^2)
+
+
+def test_fp32_and_bf16_search_agree_bit_for_bit(hip):
+    """c3dgs_weighted_distance (no scratch: fp32 matrix cores) and c3dgs_weighted_distance_ws (split bf16) return the same
+    distances and indices on data full of near ties; so does a scratch too small for the split codebook."""
+    from c3dgs_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    N, Cn, K = 20000, 4096, 48
+    cb = torch.randn(Cn, K, generator=g) * 0.1
+    cb[100:600] = cb[1000:1500] * (1 + 1e-7)
+    x = torch.randn(N, K, generator=g) * 0.1
+    i, j = torch.randint(0, Cn, (2, len(x[1::3])), generator=g)
+    x[1::3] = 0.5 * (cb[i] + cb[j])
+    x, cb = x.float().cuda(), cb.float().cuda()
+    d_b, i_b = hip.weightedDistance(x, cb)
+    d_f = torch.empty(N, dtype=torch.float32, device="cuda"); i_f = torch.empty(N, dtype=torch.int64, device="cuda")
+    _lib.check(L.c3dgs_weighted_distance(N, Cn, K, x.data_ptr(), None, cb.data_ptr(), d_f.data_ptr(), i_f.data_ptr(), None))
+    d_s = torch.empty_like(d_f); i_s = torch.empty_like(i_f)
+    small = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    _lib.check(L.c3dgs_weighted_distance_ws(N, Cn, K, x.data_ptr(), None, cb.data_ptr(), d_s.data_ptr(), i_s.data_ptr(),
+                                            small.data_ptr(), int(small.numel()), None))
+    torch.cuda.synchronize()
+    assert torch.equal(i_b, i_f) and torch.equal(d_b.view(torch.int32), d_f.view(torch.int32))
+    assert torch.equal(i_b, i_s) and torch.equal(d_b.view(torch.int32), d_s.view(torch.int32))
+
+
 _NCCL_CHILD = r"""
 import os, torch, torch.distributed as dist
 os.environ["MASTER_ADDR"] = "127.0.0.1"          # MASTER_PORT: a free port chosen by the parent test
