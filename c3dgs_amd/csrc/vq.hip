@@ -317,89 +317,142 @@ wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
     }
 }
 
-// ---------------------------------------------------------------- the same search on the bf16 matrix cores (split operands)
+// ---------------------------------------------------------------- the same search on the fp16 matrix cores (split operands)
 //
-// v_mfma_f32_32x32x16_bf16 runs 16x the multiply-adds per cycle of the fp32 form. An fp32 value is the exact sum of
-// three bf16 pieces  v = h + l + t  (h = bf16(v), l = bf16(v - h), t = bf16(v - h - l): 3 x 8 significant bits, same
-// exponent range as fp32), so a product x c is reproduced to ~2^-22 relative by the six piece products
-//     xh ch + xh cl + xl ch + xl cl + xh ct + xt ch        (dropped: xl ct, xt cl, xt ct and the split residuals)
-// each of which is EXACT in the fp32 accumulator's product stage (8 x 8 bits). Six bf16 MFMAs replace eight fp32 ones
-// per 16 dimensions: 18 x 32 cycles instead of 24 x 64 per 32 x 32 distances at K = 48. The search was never the exact
-// part of this path -- the winner's distance is recomputed with the reference's k-ordered chain and every point whose two
-// best candidates lie within the error margin is re-scanned exactly -- so only the margin has to cover the approximation:
-// the dropped terms (<= 2.4e-7 sum|x_k c_k|), the accumulation inside and between the 18 MFMAs (measured through
-// c3dgs_debug_wd_scores, tests/test_vq_gpu.py) and the 16-ulp row packing of top2_update.
+// v_mfma_f32_32x32x16_f16 runs 16x the multiply-adds per cycle of the fp32 form. With v = h + l + r, h = fp16(v),
+// l = fp16(v - h) (2 x 11 significant bits, |r| <= 2^-22 |v|), a product x c is reproduced to 3 * 2^-22 relative by the
+// three piece products
+//     xh ch + xh cl + xl ch                     (dropped: xl cl and the two split residuals)
+// each of which is EXACT in the matrix core's fp32 product stage (11 x 11 bits): three fp16 MFMAs replace eight fp32 ones
+// per 16 dimensions, 9 x 32 cycles instead of 24 x 64 per 32 x 32 distances at K = 48. (Three bf16 pieces and six products
+// give the same accuracy for twice the matrix time: 0.50 ms per 2^18 x 4096 x 48 batch, measured.)
+// fp16 has a narrow exponent range, so both operands are scaled by ONE power of two 2^e chosen per call from the
+// codebook's largest magnitude (it lands in [2^10, 2^11)); scores are compared per point, so a common exact scale changes no
+// decision. Elements far below the largest lose their low piece to fp16's subnormal spacing: an absolute error of 2^-35
+// of the largest element, nothing against the margin. Points more than ~16x beyond the codebook's largest magnitude
+// overflow to inf / NaN scores, are flagged ambiguous by the margin test and take the exact re-scan like any other flagged
+// point: the search is never the exact part of this path -- the winner's distance is recomputed with the reference's
+// k-ordered chain and every point whose two best candidates lie within the error margin is re-scanned exactly -- so
+// only the margin has to cover the approximation: the dropped terms (<= 7.2e-7 sum|x_k c_k|), the accumulation inside and
+// between the 9 MFMAs (measured through c3dgs_debug_wd_scores, tests/test_vq_gpu.py) and top2_update's 16-ulp row packing.
 // The codebook is split ONCE per call by wd_split_codebook_kernel into MFMA A-operand fragments
-//     frag[tile][sub-tile (32 codewords)][k-step (16 dims)][piece][lane][8 x bf16]    (lane l: codeword l & 31, dims 8 (l >> 5) ..+7)
+//     frag[tile][sub-tile (32 codewords)][k-step (16 dims)][piece][lane][8 x fp16]    (lane l: codeword l & 31, dims 8 (l >> 5) ..+7)
 // so staging a tile is a plain 16-byte copy and a wave's operand read is one conflict-free ds_read_b128.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BF_PIECES = 3;
-template <int MF_K> struct BfShape {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int HF_PIECES = 2;
+
+// global -> LDS copies without a register stop (global_load_lds_dwordx4 / _dword): lane l's bytes land at lds_wave_base + l * SIZE.
+// Device pass only: with the builtin inside a kernel TEMPLATE, hipcc (ROCm 7.2) silently drops the kernel's host-side launch
+// stub from the object (undefined __device_stub__ at load time), so the host pass sees empty helpers.
+__device__ __forceinline__ void lds_dma16(const void* g, void* lds_wave_base)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+__device__ __forceinline__ void lds_dma4(const void* g, void* lds_wave_base)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+#endif
+}
+template <int MF_K> struct HfShape {
     static constexpr int KS = (MF_K + 15) / 16;                                  // k-steps of 16 dims (zero-padded)
-    static constexpr int SUB_BYTES = KS * BF_PIECES * 64 * 16;                   // one 32-codeword sub-tile
-    static constexpr int TILE_BYTES = (MF_CT / 32) * SUB_BYTES;                  // 36,864 B at K = 48
+    static constexpr int SUB_BYTES = KS * HF_PIECES * 64 * 16;                   // one 32-codeword sub-tile
+    static constexpr int TILE_BYTES = (MF_CT / 32) * SUB_BYTES;                  // 24,576 B at K = 48
 };
 
-__device__ __forceinline__ void bf16_split3(float v, __bf16& h, __bf16& l, __bf16& t)
+__device__ __forceinline__ void f16_split2(float v, _Float16& h, _Float16& l)
 {
-    h = (__bf16)v;
-    const float r1 = v - (float)h;          // exact
-    l = (__bf16)r1;
-    const float r2 = r1 - (float)l;         // exact
-    t = (__bf16)r2;
+    h = (_Float16)v;
+    l = (_Float16)(v - (float)h);           // the difference is exact in fp32
+}
+
+// scale exponent from the largest |c| (its fp32 bits, gathered with atomicMax): max|c| * 2^e in [2^10, 2^11)
+__device__ __forceinline__ int wd_scale_exp(uint32_t absmax_bits)
+{
+    const int ex = (int)(absmax_bits >> 23);                  // biased exponent; 0 = zero / subnormal, 255 = inf / NaN
+    if (ex == 0 || ex == 255) return 0;
+    return max(-100, min(100, 10 - (ex - 127)));
 }
 
 size_t wd_split_bytes(int C, int K)
 {
     const int ks = (K + 15) / 16;
     const size_t ntiles = ((size_t)C + MF_CT - 1) / MF_CT;
-    return ntiles * (size_t)(MF_CT / 32) * ks * BF_PIECES * 64 * 16 + ntiles * MF_CT * sizeof(float);
+    return ntiles * (size_t)(MF_CT / 32) * ks * HF_PIECES * 64 * 16 + ntiles * MF_CT * sizeof(float) + 16;   // + the scale word
 }
 
-// one thread per (tile, sub-tile, k-step, lane): 8 dims of one codeword -> its three 16-byte fragments;
-// the first C threads also compute ||c||^2 (k-ordered FMA chain, as the fp32 kernel does per tile)
+__global__ void __launch_bounds__(256) wd_absmax_kernel(size_t n, const float* __restrict__ v, uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t s_m[4];
+    uint32_t m = 0;
+    auto take = [&](float f) { const uint32_t b = __float_as_uint(f) & 0x7fffffffu; m = max(m, b <= 0x7f800000u ? b : 0u); };   // NaNs do not set the scale
+    const size_t n4 = (((uintptr_t)v) & 15) == 0 ? n / 4 : 0;
+    const float4* v4 = reinterpret_cast<const float4*>(v);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 f = v4[i];
+        take(f.x); take(f.y); take(f.z); take(f.w);
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) take(v[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        if (m) atomicMax(out, m);
+    }
+}
+
+// one thread per (tile, sub-tile, k-step, lane): 8 dims of one codeword -> its two 16-byte fragments;
+// the first threads also compute ||c||^2 (k-ordered FMA chain, as the fp32 kernel does per tile), scaled by 2^2e
 template <int MF_K>
 __global__ void __launch_bounds__(256)
-wd_split_codebook_kernel(int C, const float* __restrict__ codebook, uint4* __restrict__ frag, float* __restrict__ norms)
+wd_split_codebook_kernel(int C, const float* __restrict__ codebook, uint4* __restrict__ frag, float* __restrict__ norms,
+                         const uint32_t* __restrict__ absmax)
 {
-    constexpr int KS = BfShape<MF_K>::KS;
+    constexpr int KS = HfShape<MF_K>::KS;
     const int ntiles = (C + MF_CT - 1) / MF_CT;
     const int t = blockIdx.x * 256 + threadIdx.x;
+    const float sc = __builtin_ldexpf(1.0f, wd_scale_exp(*absmax));
     if (t < ntiles * MF_CT) {
         float nr = 3.0e38f;                                  // rows past C never win
         if (t < C) {
             nr = 0.f;
 #pragma unroll
             for (int k = 0; k < MF_K; k++) nr = fmaf(codebook[(size_t)t * MF_K + k], codebook[(size_t)t * MF_K + k], nr);
+            nr = (nr * sc) * sc;                             // exact: power of two, (max|c| 2^e)^2 K << FLT_MAX
         }
         norms[t] = nr;
     }
     if (t >= ntiles * (MF_CT / 32) * KS * 64) return;
     const int lane = t & 63, q = (t >> 6) % KS, ts = (t >> 6) / KS;      // ts = tile * 4 + sub
     const int cw = ts * 32 + (lane & 31), k0 = 16 * q + 8 * (lane >> 5);
-    union { bf16x8 v; uint4 u; } p[BF_PIECES];
+    union { f16x8 v; uint4 u; } p[HF_PIECES];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const float v = (cw < C && k0 + j < MF_K) ? codebook[(size_t)cw * MF_K + k0 + j] : 0.f;
-        __bf16 h, l, tt;
-        bf16_split3(v, h, l, tt);
-        p[0].v[j] = h; p[1].v[j] = l; p[2].v[j] = tt;
+        const float v = (cw < C && k0 + j < MF_K) ? codebook[(size_t)cw * MF_K + k0 + j] * sc : 0.f;
+        _Float16 h, l;
+        f16_split2(v, h, l);
+        p[0].v[j] = h; p[1].v[j] = l;
     }
 #pragma unroll
-    for (int e = 0; e < BF_PIECES; e++) frag[((size_t)(ts * KS + q) * BF_PIECES + e) * 64 + lane] = p[e].u;
+    for (int e = 0; e < HF_PIECES; e++) frag[((size_t)(ts * KS + q) * HF_PIECES + e) * 64 + lane] = p[e].u;
 }
 
-// SCORES != nullptr (diagnostics, one workgroup's worth of points): also dumps s[n][c] = ||c||^2 - 2 x_n.c as the matrix cores
-// produced it, so a test can measure the approximation error the margin has to cover.
+// SCORES (diagnostics, one workgroup's worth of points): also dumps s[n][c] = ||c||^2 - 2 x_n.c as the matrix cores produced it
+// (unscaled), so a test can measure the approximation error the margin has to cover.
 template <int MF_K, bool SPLIT, bool SCORES>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 74 KB of LDS: two workgroups per CU
-wd_bf16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather,
-               const float* __restrict__ codebook, const uint4* __restrict__ frag, const float* __restrict__ norms,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 173 VGPRs (two accumulator pairs); three waves per SIMD with fragments loaded per k-step measured the same
+wd_f16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather,
+              const float* __restrict__ codebook, const uint4* __restrict__ frag, const float* __restrict__ norms,
+              const uint32_t* __restrict__ absmax,
                float* __restrict__ out_dist, int64_t* __restrict__ out_idx, int* __restrict__ flag_list, int flag_cap,
                float margin_rel, float* __restrict__ scores)
 {
-    constexpr int KS = BfShape<MF_K>::KS;
-    constexpr int TILE_V = BfShape<MF_K>::TILE_BYTES / 16, SUB_V = BfShape<MF_K>::SUB_BYTES / 16;
+    constexpr int KS = HfShape<MF_K>::KS;
+    constexpr int TILE_V = HfShape<MF_K>::TILE_BYTES / 16, SUB_V = HfShape<MF_K>::SUB_BYTES / 16;
     constexpr int STAGE_PER_THREAD = (TILE_V + 255) / 256;
     __shared__ uint4 s_frag[2][TILE_V];
     __shared__ float s_norm[2][MF_CT];
@@ -410,8 +463,10 @@ wd_bf16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
     const int i = lane & 31, h = lane >> 5;
     const int64_t n_base = SPLIT ? (int64_t)blockIdx.x * MF_PTS : ((int64_t)blockIdx.x * 4 + wave) * MF_PTS;
 
-    // B operands: the three pieces of -2 x[n_base + 32 g + i][16 q + 8 h + j], j = 0..7
-    bf16x8 bh[2][KS], bl[2][KS], bt[2][KS];
+    // B operands: the two pieces of -2 * 2^e * x[n_base + 32 g + i][16 q + 8 h + j], j = 0..7
+    const int sexp = wd_scale_exp(*absmax);
+    const float sc2 = -2.0f * __builtin_ldexpf(1.0f, sexp), unscale = __builtin_ldexpf(1.0f, -sexp);
+    f16x8 bh[2][KS], bl[2][KS];
     float xnorm[2];
     int64_t rows[2];
 #pragma unroll
@@ -427,9 +482,9 @@ wd_bf16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
                 const int k = 16 * q + 8 * h + j;
                 const float v = k < MF_K ? coefs[row * MF_K + k] : 0.f;
                 part = fmaf(v, v, part);
-                __bf16 ph, pl, pt;
-                bf16_split3(-2.0f * v, ph, pl, pt);
-                bh[g][q][j] = ph; bl[g][q][j] = pl; bt[g][q][j] = pt;
+                _Float16 ph, pl;
+                f16_split2(sc2 * v, ph, pl);
+                bh[g][q][j] = ph; bl[g][q][j] = pl;
             }
         }
         xnorm[g] = part + __shfl_xor(part, 32);
@@ -441,76 +496,123 @@ wd_bf16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
 
     const int ntiles = (C + MF_CT - 1) / MF_CT;
     static_assert(TILE_V % 256 == 0, "whole 16-byte vectors per thread");
-    uint4 st[STAGE_PER_THREAD];
-    float st_norm = 0.f;
-#define C3DGS_BF_STAGE_LOAD(tile_)                                                                                        \
+    // staging: global -> LDS directly (global_load_lds_dwordx4: no staging registers; the LDS image is lane-linear, i.e. a wave's
+    // 64 x 16 bytes land at a wave-uniform base + lane * 16, exactly the fragment order wd_split_codebook_kernel wrote)
+#define C3DGS_HF_STAGE(tile_, buf_)                                                                                       \
     {                                                                                                                     \
         const uint4* src_ = frag + (size_t)(tile_) * TILE_V + tid;                                                        \
-        _Pragma("unroll") for (int e = 0; e < STAGE_PER_THREAD; e++) st[e] = src_[e * 256];                               \
-        if (tid < MF_CT) st_norm = norms[(size_t)(tile_) * MF_CT + tid];                                                  \
+        _Pragma("unroll") for (int e = 0; e < STAGE_PER_THREAD; e++)                                                      \
+            lds_dma16(src_ + e * 256, &s_frag[buf_][e * 256 + wave * 64]);                                                \
+        if (wave < MF_CT / 64)                                                                                            \
+            lds_dma4(norms + (size_t)(tile_) * MF_CT + tid, &s_norm[buf_][wave * 64]);                                    \
     }
-#define C3DGS_BF_STAGE_STORE(buf_)                                                                                        \
-    {                                                                                                                     \
-        _Pragma("unroll") for (int e = 0; e < STAGE_PER_THREAD; e++) s_frag[buf_][e * 256 + tid] = st[e];                 \
-        if (tid < MF_CT) s_norm[buf_][tid] = st_norm;                                                                     \
-    }
-    C3DGS_BF_STAGE_LOAD(0);
-    C3DGS_BF_STAGE_STORE(0);
+    C3DGS_HF_STAGE(0, 0);
     __syncthreads();
+#define C3DGS_HF_INIT(A0, A1, buf_, sub_)                                                                                 \
+    _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                                      \
+        const float nv_ = s_norm[buf_][(sub_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];                                     \
+        A0[r] = nv_; A1[r] = nv_;                                                                                         \
+    }
+#define C3DGS_HF_UPD(P0, P1, r_)                                                                                          \
+    top2_update(P0[r_], (uint32_t)(r_), keep_mask, best[0], second[0]);                                                   \
+    top2_update(P1[r_], (uint32_t)(r_), keep_mask, best[1], second[1]);
+    // rows past C hold zeros with a norm of 3e38 (wd_split_codebook_kernel): they lose against every real codeword, so the
+    // last tile needs no special case; the pipeline starts on a sub-tile's worth of such scores
+    f32x16 pa0, pa1, pb0, pb1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { pb0[r] = 3.0e38f; pb1[r] = 3.0e38f; }
     for (int tile = 0; tile < ntiles; tile++) {
         const int buf = tile & 1;
-        C3DGS_BF_STAGE_LOAD(min(tile + 1, ntiles - 1));        // in flight behind this tile's MFMAs (last tile: re-read, unused)
+        if (tile + 1 < ntiles) C3DGS_HF_STAGE(tile + 1, buf ^ 1);   // in flight behind this tile's MFMAs; the buffer was last read before the previous barrier
+        if constexpr (SPLIT || SCORES) {
 #pragma unroll 1
-        for (int sub = SPLIT ? wave : 0; sub < (SPLIT ? wave + 1 : MF_CT / 32); sub++) {
-            if (tile * MF_CT + sub * 32 >= C) break;
-            f32x16 acc0, acc1;
+            for (int sub = SPLIT ? wave : 0; sub < (SPLIT ? wave + 1 : MF_CT / 32); sub++) {
+                C3DGS_HF_INIT(pa0, pa1, buf, sub);
+                const uint4* fsub = &s_frag[buf][sub * SUB_V + lane];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float nv = s_norm[buf][sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-                acc0[r] = nv; acc1[r] = nv;
-            }
-            const uint4* fsub = &s_frag[buf][sub * SUB_V + lane];
-#pragma unroll
-            for (int q = 0; q < KS; q++) {
-                union { uint4 u; bf16x8 v; } ah, al, at;
-                ah.u = fsub[(q * BF_PIECES + 0) * 64];
-                al.u = fsub[(q * BF_PIECES + 1) * 64];
-                at.u = fsub[(q * BF_PIECES + 2) * 64];
-                // smallest pieces first
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.v, bh[0][q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at.v, bh[1][q], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bt[0][q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bt[1][q], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bl[0][q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bl[1][q], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh[0][q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh[1][q], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl[0][q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl[1][q], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh[0][q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh[1][q], acc1, 0, 0, 0);
-            }
-            if (SCORES) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int c = tile * MF_CT + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int64_t n0 = n_base + i, n1 = n_base + 32 + i;
-                    if (c < C && n0 < N) scores[n0 * C + c] = acc0[r];
-                    if (c < C && n1 < N) scores[n1 * C + c] = acc1[r];
+                for (int q = 0; q < KS; q++) {
+                    union { uint4 u; f16x8 v; } ah, al;
+                    ah.u = fsub[(q * HF_PIECES + 0) * 64];
+                    al.u = fsub[(q * HF_PIECES + 1) * 64];
+                    pa0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh[0][q], pa0, 0, 0, 0);
+                    pa1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh[1][q], pa1, 0, 0, 0);
+                    pa0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl[0][q], pa0, 0, 0, 0);
+                    pa1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl[1][q], pa1, 0, 0, 0);
+                    pa0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh[0][q], pa0, 0, 0, 0);
+                    pa1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh[1][q], pa1, 0, 0, 0);
                 }
-            }
-            const float was0 = best[0], was1 = best[1];
+                if (SCORES) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                top2_update(acc0[r], (uint32_t)r, keep_mask, best[0], second[0]);
-                top2_update(acc1[r], (uint32_t)r, keep_mask, best[1], second[1]);
+                    for (int r = 0; r < 16; r++) {
+                        const int c = tile * MF_CT + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int64_t n0 = n_base + i, n1 = n_base + 32 + i;
+                        if (c < C && n0 < N) scores[n0 * C + c] = (pa0[r] * unscale) * unscale;
+                        if (c < C && n1 < N) scores[n1 * C + c] = (pa1[r] * unscale) * unscale;
+                    }
+                }
+                const float was0 = best[0], was1 = best[1];
+#pragma unroll
+                for (int r = 0; r < 16; r++) { C3DGS_HF_UPD(pa0, pa1, r); }
+                const int gid = tile * (MF_CT / 32) + sub;
+                grp[0] = best[0] < was0 ? gid : grp[0];
+                grp[1] = best[1] < was1 ? gid : grp[1];
             }
-            const int gid = tile * (MF_CT / 32) + sub;
-            grp[0] = best[0] < was0 ? gid : grp[0];
-            grp[1] = best[1] < was1 ? gid : grp[1];
+        } else {
+            // One sub-tile = 32 codewords x 64 points: 6 KS MFMAs (per k-step {cl xh, ch xl, ch xh} for both 32-point groups,
+            // smallest pieces first) and 32 x 3 vector instructions of top-2 update. An MFMA leaves 24 of its 32 cycles of
+            // vector issue free, so the update of the PREVIOUS sub-tile's scores (PRV) is interleaved into this sub-tile's
+            // MFMAs (ACC): one accumulator row of both groups = six vector instructions behind each of the first 16 MFMAs. The
+            // placement is held by an empty asm that ties the MFMA's accumulator to the running top-2 (otherwise instruction
+            // selection hoists the 32 row packings and 32 minima in front of the medians and spills 60 registers) plus a
+            // sched_barrier per group; two accumulator pairs alternate, nothing is copied. Measured per 2^18 x 4096 x 48 batch
+            // (MI355X, ~1.6 GHz under this load): 0.325 ms un-pipelined (MFMAs, then the update, other waves filling in),
+            // 0.281 pipelined, 0.272 with LDS-DMA staging; the MFMAs alone 0.247, the updates alone 0.140 (temporary ablation
+            // builds) -- i.e. what is left is the matrix pipe at the clock the chip holds.
+#define C3DGS_HF_STEP(ACC0, ACC1, PRV0, PRV1, sub_, gid_prev_)                                                            \
+            {                                                                                                             \
+                C3DGS_HF_INIT(ACC0, ACC1, buf, sub_);                                                                     \
+                const f16x8* fsub_ = reinterpret_cast<const f16x8*>(&s_frag[buf][(sub_) * SUB_V + lane]);                 \
+                f16x8 ah_[KS], al_[KS];                                                                                   \
+                _Pragma("unroll") for (int q = 0; q < KS; q++) {                                                          \
+                    ah_[q] = fsub_[(q * HF_PIECES + 0) * 64];                                                             \
+                    al_[q] = fsub_[(q * HF_PIECES + 1) * 64];                                                             \
+                }                                                                                                         \
+                const float was0_ = best[0], was1_ = best[1];                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                                        \
+                _Pragma("unroll") for (int q = 0; q < KS; q++) {                                                          \
+                    _Pragma("unroll") for (int j = 0; j < 6; j++) {                                                       \
+                        const f16x8 a_ = j < 2 ? al_[q] : ah_[q];                                                         \
+                        const f16x8 b_ = (j >> 1) == 1 ? bl[j & 1][q] : bh[j & 1][q];                                     \
+                        if (j & 1) ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, ACC1, 0, 0, 0);                  \
+                        else ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, ACC0, 0, 0, 0);                        \
+                        const int r_ = q * 6 + j;                                                                         \
+                        if (r_ < 16) { C3DGS_HF_UPD(PRV0, PRV1, r_); }                                                    \
+                        /* ordering fence (no instruction): ties this MFMA's accumulator and the running top-2 together, */ \
+                        /* so instruction selection cannot move the update away from its MFMA                            */ \
+                        if (j & 1) asm volatile("" : "+v"(ACC1), "+v"(best[0]), "+v"(second[0]), "+v"(best[1]), "+v"(second[1])); \
+                        else asm volatile("" : "+v"(ACC0), "+v"(best[0]), "+v"(second[0]), "+v"(best[1]), "+v"(second[1])); \
+                        __builtin_amdgcn_sched_barrier(0);                                                                \
+                    }                                                                                                     \
+                }                                                                                                         \
+                if (6 * KS < 16) { _Pragma("unroll") for (int r_ = 6 * KS; r_ < 16; r_++) { C3DGS_HF_UPD(PRV0, PRV1, r_); } } \
+                grp[0] = best[0] < was0_ ? (gid_prev_) : grp[0];                                                          \
+                grp[1] = best[1] < was1_ ? (gid_prev_) : grp[1];                                                          \
+            }
+            const int g0 = tile * (MF_CT / 32);
+            C3DGS_HF_STEP(pa0, pa1, pb0, pb1, 0, g0 - 1);   // g0 - 1 = -1 on the first tile: those scores never win
+            C3DGS_HF_STEP(pb0, pb1, pa0, pa1, 1, g0 + 0);
+            C3DGS_HF_STEP(pa0, pa1, pb0, pb1, 2, g0 + 1);
+            C3DGS_HF_STEP(pb0, pb1, pa0, pa1, 3, g0 + 2);
         }
-        C3DGS_BF_STAGE_STORE(buf ^ 1);                         // the other buffer was last read before the previous barrier
-        __syncthreads();
+        __syncthreads();                                       // drains the LDS-DMA (vmcnt) first
+    }
+    if constexpr (!(SPLIT || SCORES)) {
+        const float was0 = best[0], was1 = best[1];
+#pragma unroll
+        for (int r = 0; r < 16; r++) { C3DGS_HF_UPD(pb0, pb1, r); }
+        const int gid = ntiles * (MF_CT / 32) - 1;
+        grp[0] = best[0] < was0 ? gid : grp[0];
+        grp[1] = best[1] < was1 ? gid : grp[1];
     }
 #pragma unroll
     for (int g = 0; g < 2; g++) {
@@ -538,6 +640,7 @@ wd_bf16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
         }
         const int64_t n = n_base + 32 * g + i;
         if (h == 0 && n < N) {
+            nb = (nb * unscale) * unscale; ns = (ns * unscale) * unscale;   // exact powers of two
             const float db = nb + xnorm[g], ds = ns + xnorm[g];
             const float margin = margin_rel * (fabsf(db) + fabsf(ds) + 2.0f * xnorm[g]) + 1e-37f;
             const bool ambiguous = !(ns - nb > margin);
@@ -690,13 +793,28 @@ wd_fixup_list_kernel(int C, const float* __restrict__ coefs, const int64_t* __re
     }
 }
 
-// margin of the split-bf16 search, relative to (d_best + d_second + 2 ||x||^2): measured worst error of a score
-// 1.2e-6 of that scale (tests/test_vq_gpu.py::test_bf16_scores_within_margin) + the 16-ulp row packing 1.9e-6 + the
-// exact chain's own rounding (the fp32 search's 4e-5 covered a 48-step chain on both sides with the same headroom)
-constexpr float WD_BF16_MARGIN = 4e-5f;
+// margin of the split-fp16 search, relative to (d_best + d_second + 2 ||x||^2): the measured worst error of a score is
+// ~1e-6 of that scale (tests/test_vq_gpu.py::test_split_scores_within_margin), the 16-ulp row packing adds 1.9e-6, the
+// exact chain's own rounding the rest (the fp32 search's 4e-5 covers a 48-step chain on both sides with the same headroom)
+constexpr float WD_SPLIT_MARGIN = 4e-5f;
+
+// scratch layout of the split search: [fragments][scaled norms][scale word (largest |c| bits), 16 bytes]
+template <int K>
+static void launch_wd_split_codebook(int C, const float* codebook, void* ws, uint4*& frag, float*& norms, uint32_t*& absmax, hipStream_t s)
+{   // the caller has cleared the scale word (it is the last 16 bytes of the split region, directly in front of the list)
+    const int ntiles = (C + MF_CT - 1) / MF_CT;
+    const size_t frag_bytes = (size_t)ntiles * HfShape<K>::TILE_BYTES;
+    frag = (uint4*)ws;
+    norms = (float*)((char*)ws + frag_bytes);
+    absmax = (uint32_t*)(norms + (size_t)ntiles * MF_CT);
+    const size_t n = (size_t)C * K;
+    wd_absmax_kernel<<<(unsigned)std::min<size_t>((n + 4095) / 4096, 64), 256, 0, s>>>(n, codebook, absmax);
+    const unsigned gs = (unsigned)((ntiles * (MF_CT / 32) * HfShape<K>::KS * 64 + 255) / 256);
+    wd_split_codebook_kernel<K><<<std::max(gs, (unsigned)((ntiles * MF_CT + 255) / 256)), 256, 0, s>>>(C, codebook, frag, norms, absmax);
+}
 
 // ws (optional device scratch, 16-byte aligned): [split codebook: wd_split_bytes(C, K)][int32 list of ambiguous points: 1 + cap].
-// With room for the split codebook the search runs on the bf16 matrix cores, otherwise on the fp32 ones; whatever is
+// With room for the split codebook the search runs on the fp16 matrix cores, otherwise on the fp32 ones; whatever is
 // left holds the list (without a list the flagged points are re-scanned one by one).
 template <int K>
 static void launch_wd_mfma(int64_t N, int C, const float* coefs, const int64_t* gather, const float* codebook, float* out_dist,
@@ -708,24 +826,23 @@ static void launch_wd_mfma(int64_t N, int C, const float* coefs, const int64_t* 
     // profiles/r02a_vq_slices.txt)
     static const int split_env = []() { const char* e = getenv("C3DGS_VQ_SPLIT"); return e ? atoi(e) : -1; }();   // A/B switch for tests
     static const bool force_f32 = getenv("C3DGS_VQ_F32_MFMA") != nullptr;                                          // A/B switch
-    static const float margin_env = []() { const char* e = getenv("C3DGS_VQ_BF16_MARGIN"); return e ? (float)atof(e) : WD_BF16_MARGIN; }();
+    static const float margin_env = []() { const char* e = getenv("C3DGS_VQ_SPLIT_MARGIN"); return e ? (float)atof(e) : WD_SPLIT_MARGIN; }();
     const bool split = split_env >= 0 ? split_env != 0 : g1 < 256;
     const size_t sb = wd_split_bytes(C, K);
-    const bool bf16 = K >= 12 && ws && ws_bytes >= sb && (((uintptr_t)ws) & 15) == 0 && !force_f32;
-    char* rest = (char*)ws + (bf16 ? sb : 0);
-    const size_t rest_bytes = ws ? ws_bytes - (bf16 ? sb : 0) : 0;
+    const bool f16 = K >= 12 && ws && ws_bytes >= sb && (((uintptr_t)ws) & 15) == 0 && !force_f32;
+    char* rest = (char*)ws + (f16 ? sb : 0);
+    const size_t rest_bytes = ws ? ws_bytes - (f16 ? sb : 0) : 0;
     int* flag_list = rest_bytes >= 2 * sizeof(int) && N < ((int64_t)1 << 31) ? (int*)rest : nullptr;
     const int flag_cap = flag_list ? (int)std::min<size_t>(rest_bytes / sizeof(int) - 1, (size_t)0x7fffffff) : 0;
     const bool listed = flag_list != nullptr;
-    if (listed) (void)hipMemsetAsync(flag_list, 0, sizeof(int), s);
-    if (bf16) {
-        uint4* frag = (uint4*)ws;
-        float* norms = (float*)((char*)ws + sb) - (size_t)((C + MF_CT - 1) / MF_CT) * MF_CT;
-        const int ntiles = (C + MF_CT - 1) / MF_CT;
-        const unsigned gs = (unsigned)((ntiles * (MF_CT / 32) * BfShape<K>::KS * 64 + 255) / 256);
-        wd_split_codebook_kernel<K><<<std::max(gs, (unsigned)((ntiles * MF_CT + 255) / 256)), 256, 0, s>>>(C, codebook, frag, norms);
-        if (split) wd_bf16_kernel<K, true, false><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, frag, norms, out_dist, out_idx, flag_list, flag_cap, margin_env, nullptr);
-        else wd_bf16_kernel<K, false, false><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, frag, norms, out_dist, out_idx, flag_list, flag_cap, margin_env, nullptr);
+    // one fill clears the scale word (last 16 bytes of the split region) and the list's counter behind it
+    if (f16) (void)hipMemsetAsync((char*)ws + sb - 16, 0, 16 + (listed ? std::min<size_t>(rest_bytes, 16) : 0), s);   // up to 32 bytes: one aligned fill (the first list entries are rewritten by the search)
+    else if (listed) (void)hipMemsetAsync(flag_list, 0, sizeof(int), s);
+    if (f16) {
+        uint4* frag; float* norms; uint32_t* absmax;
+        launch_wd_split_codebook<K>(C, codebook, ws, frag, norms, absmax, s);
+        if (split) wd_f16_kernel<K, true, false><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, frag, norms, absmax, out_dist, out_idx, flag_list, flag_cap, margin_env, nullptr);
+        else wd_f16_kernel<K, false, false><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, frag, norms, absmax, out_dist, out_idx, flag_list, flag_cap, margin_env, nullptr);
     } else if (split) wd_mfma_kernel<K, true><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
     else wd_mfma_kernel<K, false><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
     if (listed) {
@@ -764,18 +881,15 @@ int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const 
     return 0;
 }
 
-// diagnostics: the scores s[n][c] = ||c||^2 - 2 x_n.c exactly as the split-bf16 search forms them (K = 48, N <= 256 points)
+// diagnostics: the scores s[n][c] = ||c||^2 - 2 x_n.c exactly as the split-fp16 search forms them (K = 48, N <= 256 points)
 int launch_wd_debug_scores(int64_t N, int C, int K, const float* coefs, const float* codebook, float* scores, void* ws, size_t ws_bytes,
                            float* out_dist, int64_t* out_idx, hipStream_t s)
 {
     if (K != 48 || N <= 0 || N > 256 || C < 32 || !ws || ws_bytes < wd_split_bytes(C, K) || (((uintptr_t)ws) & 15)) return 1;
-    const size_t sb = wd_split_bytes(C, K);
-    uint4* frag = (uint4*)ws;
-    const int ntiles = (C + MF_CT - 1) / MF_CT;
-    float* norms = (float*)((char*)ws + sb) - (size_t)ntiles * MF_CT;
-    const unsigned gs = (unsigned)((ntiles * (MF_CT / 32) * BfShape<48>::KS * 64 + 255) / 256);
-    wd_split_codebook_kernel<48><<<std::max(gs, (unsigned)((ntiles * MF_CT + 255) / 256)), 256, 0, s>>>(C, codebook, frag, norms);
-    wd_bf16_kernel<48, false, true><<<1, 256, 0, s>>>(N, C, coefs, nullptr, codebook, frag, norms, out_dist, out_idx, nullptr, 0, WD_BF16_MARGIN, scores);
+    uint4* frag; float* norms; uint32_t* absmax;
+    (void)hipMemsetAsync((char*)ws + wd_split_bytes(C, K) - 16, 0, 16, s);
+    launch_wd_split_codebook<48>(C, codebook, ws, frag, norms, absmax, s);
+    wd_f16_kernel<48, false, true><<<1, 256, 0, s>>>(N, C, coefs, nullptr, codebook, frag, norms, absmax, out_dist, out_idx, nullptr, 0, WD_SPLIT_MARGIN, scores);
     return 0;
 }
 

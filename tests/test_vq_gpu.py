@@ -228,9 +228,9 @@ def test_weighted_distance_nan_rows_fall_back_to_codeword_zero(hip):
     assert torch.equal(i[ok.cuda()], i2) and torch.equal(d[ok.cuda()], d2)
 
 
-def test_bf16_scores_within_margin(hip):
-    """The candidate search of K = 48 / 12 runs on the bf16 matrix cores with every operand split into three bf16 pieces and
-    six piece products per multiply (csrc/vq.hip). Its scores s[n][c] = ||c||^2 - 2 x_n.c only have to be accurate enough
+def test_split_scores_within_margin(hip):
+    """The candidate search of K = 48 / 12 runs on the fp16 matrix cores with every operand (scaled by a common power of two)
+    split into two fp16 pieces and three piece products per multiply (csrc/vq.hip). Its scores s[n][c] = ||c||^2 - 2 x_n.c only have to be accurate enough
     for the ambiguity margin (4e-5 of d + 2||x||^2 per candidate pair) to be a valid bound: measure them against float64."""
     import ctypes as C
     from c3dgs_amd import _lib
@@ -256,12 +256,12 @@ def test_bf16_scores_within_margin(hip):
         rel = (scores.double().cpu() - exact).abs() / (d + 2.0 * (xd ** 2).sum(-1)[:, None])
         assert torch.isfinite(rel).all()
         worst = max(worst, float(rel.max()))
-    print(f"split-bf16 score error: {worst:.3e} of (d + 2||x||^2)")
+    print(f"split-fp16 score error: {worst:.3e} of (d + 2||x||^2)")
     assert worst < 5e-6, worst                                    # the margin is 4e-5 of (d_best + d_second + 2||x||^2)
 
 
-def test_fp32_and_bf16_search_agree_bit_for_bit(hip):
-    """c3dgs_weighted_distance (no scratch: fp32 matrix cores) and c3dgs_weighted_distance_ws (split bf16) return the same
+def test_fp32_and_split_search_agree_bit_for_bit(hip):
+    """c3dgs_weighted_distance (no scratch: fp32 matrix cores) and c3dgs_weighted_distance_ws (split fp16) return the same
     distances and indices on data full of near ties; so does a scratch too small for the split codebook."""
     from c3dgs_amd import _lib
     L = _lib.lib()
