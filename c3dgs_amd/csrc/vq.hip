@@ -829,7 +829,7 @@ static void launch_wd_mfma(int64_t N, int C, const float* coefs, const int64_t* 
     static const float margin_env = []() { const char* e = getenv("C3DGS_VQ_SPLIT_MARGIN"); return e ? (float)atof(e) : WD_SPLIT_MARGIN; }();
     const bool split = split_env >= 0 ? split_env != 0 : g1 < 256;
     const size_t sb = wd_split_bytes(C, K);
-    const bool f16 = K >= 12 && ws && ws_bytes >= sb && (((uintptr_t)ws) & 15) == 0 && !force_f32;
+    const bool f16 = ws && ws_bytes >= sb && (((uintptr_t)ws) & 15) == 0 && !force_f32;
     char* rest = (char*)ws + (f16 ? sb : 0);
     const size_t rest_bytes = ws ? ws_bytes - (f16 ? sb : 0) : 0;
     int* flag_list = rest_bytes >= 2 * sizeof(int) && N < ((int64_t)1 << 31) ? (int*)rest : nullptr;
@@ -855,7 +855,7 @@ static void launch_wd_mfma(int64_t N, int C, const float* coefs, const int64_t* 
 size_t wd_ws_bytes(int64_t N, int C, int K)
 {
     const size_t list = ((size_t)(N > 0 ? N : 0) / 8 + 2) * sizeof(int);           // ~1-2 % of the points are ambiguous
-    return ((K == 48 || K == 12) ? wd_split_bytes(C, K) : 0) + list;
+    return ((K == 48 || K == 12 || K == 6) ? wd_split_bytes(C, K) : 0) + list;
 }
 
 int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const int64_t* gather, const float* codebook,

@@ -260,6 +260,32 @@ def test_split_scores_within_margin(hip):
     assert worst < 5e-6, worst                                    # the margin is 4e-5 of (d_best + d_second + 2||x||^2)
 
 
+@pytest.mark.parametrize("K", [48, 12, 6])
+def test_split_search_extreme_magnitudes(hip, orc, K):
+    """The fp16 pieces share ONE power-of-two scale taken from the codebook's largest magnitude. Whatever falls outside fp16's
+    range after scaling -- points far larger than every codeword (inf / NaN scores), data near the fp32 limits, a codebook of
+    zeros, an inf in the codebook -- must come out of the exact re-scan with the reference's answer, never a wrong index."""
+    g = torch.Generator().manual_seed(100 + K)
+    N, C = 3000, 300
+    for scale_x, scale_c in [(1e-18, 1e-18), (1e15, 1e15), (1e3, 1.0), (1.0, 1e-4), (1e-30, 1e-30), (1.0, 0.0)]:
+        x = (torch.randn(N, K, generator=g) * scale_x).float()
+        cb = (torch.randn(C, K, generator=g) * scale_c).float()
+        x[::7] = cb[torch.randint(0, C, (len(x[::7]),), generator=g)]
+        x[5, 0] = 3.0e38                                                   # one point at the edge of fp32
+        d_ref, i_ref = orc.weighted_distance(x.numpy(), cb.numpy())
+        d, i = hip.weightedDistance(x.cuda(), cb.cuda())
+        what = f"K={K} scale_x={scale_x} scale_c={scale_c}"
+        np.testing.assert_array_equal(i.cpu().numpy(), i_ref, err_msg=what)
+        np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), d_ref.view(np.uint32), err_msg=what)
+    x = (torch.randn(N, K, generator=g) * 0.1).float()
+    cb = (torch.randn(C, K, generator=g) * 0.1).float()
+    cb[17, 1] = float("inf")                                               # an inf codeword: distance inf (or NaN) to everything
+    d_ref, i_ref = orc.weighted_distance(x.numpy(), cb.numpy())
+    d, i = hip.weightedDistance(x.cuda(), cb.cuda())
+    np.testing.assert_array_equal(i.cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), d_ref.view(np.uint32))
+
+
 def test_fp32_and_split_search_agree_bit_for_bit(hip):
     """c3dgs_weighted_distance (no scratch: fp32 matrix cores) and c3dgs_weighted_distance_ws (split fp16) return the same
     distances and indices on data full of near ties; so does a scratch too small for the split codebook."""
