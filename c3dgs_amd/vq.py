@@ -15,6 +15,7 @@ Same names, argument meaning and error behaviour.  Additions (new functionality,
 There is no CPU path: tensors must live on the GPU and libc3dgs_hip.so must be present.
 """
 import ctypes as C
+import concurrent.futures as _futures
 import gc
 import time
 from dataclasses import dataclass
@@ -219,21 +220,39 @@ class _BatchDraws:
         self.left, self.next = C.c_int64(left), C.c_int64(nxt)
         self.ring = [(torch.empty(chunk, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(self.RING)]
         self.k = 0
+        # The fill of batch k + 1 (0.26 ms for 2^20 draws, sequential by nature) runs on ONE worker thread while the caller
+        # queues the kernels of batch k: ctypes releases the GIL for the call, so the two really overlap (a covariance Lloyd
+        # step is host-bound otherwise: 0.79 -> 0.63 ms). The draws are the same stream in the same order; nothing is drawn
+        # beyond `steps` batches and a batch drawn ahead of a loop that stops early is taken back by finish(), so the state
+        # written back is exactly the reference's.
+        self.steps = int(steps)
+        self._pool = _futures.ThreadPoolExecutor(max_workers=1) if self.steps > 1 else None
+        self._pending = None
+
+    def _fill(self, k, ahead=False):
+        host, ev = self.ring[k % self.RING]
+        if k >= self.RING:
+            ev.synchronize()                             # the copy out of this buffer four steps ago
+        if ahead:                                        # a batch nobody may ask for (the loop can stop early): finish() takes it back
+            self._snap = (self.key.clone(), self.left.value, self.next.value)
+        _lib.check(_lib.lib().c3dgs_mt19937_fill(self.key.data_ptr(), C.byref(self.left), C.byref(self.next), host.data_ptr(), self.chunk))
+        return host, ev
 
     def next_batch(self):
         if self.device_rng:
             return torch.randint(low=0, high=self.N, size=[self.chunk], device=self.device)
         if self.key is None:
             return torch.randint(low=0, high=self.N, size=[self.chunk]).to(self.device)
-        host, ev = self.ring[self.k % self.RING]
-        if self.k >= self.RING:
-            ev.synchronize()                             # the copy out of this buffer four steps ago
+        k = self.k
         self.k += 1
+        host, ev = self._pending.result() if self._pending is not None else self._fill(k)
+        self._pending = None
         L = _lib.lib()
-        _lib.check(L.c3dgs_mt19937_fill(self.key.data_ptr(), C.byref(self.left), C.byref(self.next), host.data_ptr(), self.chunk))
         with torch.cuda.device(self.device):
             raw = host.to(self.device, non_blocking=True)
             ev.record()
+            if self._pool is not None and k + 1 < self.steps:
+                self._pending = self._pool.submit(self._fill, k + 1, True)  # after ev.record(): buffer (k + 1) % RING is another one
             out = torch.empty(self.chunk, dtype=torch.int64, device=self.device)
             _lib.check(L.c3dgs_draws_to_indices(self.chunk, self.N, raw.data_ptr(), out.data_ptr(),
                                                 torch.cuda.current_stream(self.device).cuda_stream))
@@ -243,6 +262,14 @@ class _BatchDraws:
         """Write the advanced generator state back to torch (call once, also on error paths)."""
         if self.key is None:
             return
+        if self._pending is not None:                    # a batch drawn ahead that nobody took: back to the state in front of it
+            self._pending.result()
+            self._pending = None
+            self.key, left, nxt = self._snap
+            self.left, self.next = C.c_int64(left), C.c_int64(nxt)
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         w = self._st.view(torch.int64)
         self._st.view(torch.int32)[_MT_LEFT] = self.left.value
         w[_MT_NEXT] = self.next.value
