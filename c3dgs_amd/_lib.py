@@ -126,6 +126,7 @@ PROTOTYPES = {
     "c3dgs_profile_read": (C.c_int, [C.POINTER(StageTime), C.c_int]),
     "c3dgs_last_error": (C.c_char_p, []),
     "c3dgs_abi_version": (C.c_int, []),
+    "c3dgs_abs_accumulate": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -81,4 +81,27 @@ void launch_adam(int n_tensors, const c3dgs_adam_tensor* tensors, double beta1, 
     adam_kernel<<<nb, 256, 0, s>>>(J, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps);
 }
 
+// acc += |g| (the accumulation step of the sensitivity pass, compress.py:110-113): one read of g, one read-modify-write of
+// acc instead of torch's abs() temporary + add_ (4 passes over P x 48 floats per camera)
+__global__ void __launch_bounds__(256) abs_accumulate_kernel(int64_t n4, int64_t n, const float* __restrict__ g, float* __restrict__ acc)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        const float4 a = reinterpret_cast<const float4*>(g)[i];
+        float4 b = reinterpret_cast<float4*>(acc)[i];
+        b.x += fabsf(a.x); b.y += fabsf(a.y); b.z += fabsf(a.z); b.w += fabsf(a.w);
+        reinterpret_cast<float4*>(acc)[i] = b;
+    }
+    if (i == 0) for (int64_t k = n4 * 4; k < n; k++) acc[k] += fabsf(g[k]);
+}
+
+void launch_abs_accumulate(int64_t n, const float* g, float* acc, hipStream_t s)
+{
+    if (n <= 0) return;
+    const bool al = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(acc)) & 15u) == 0;
+    const int64_t n4 = al ? n / 4 : 0;
+    const int64_t threads = n4 > 0 ? n4 : 1;
+    abs_accumulate_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(n4, n, g, acc);
+}
+
 } // namespace c3dgs

@@ -525,6 +525,14 @@ int c3dgs_morton_order(int32_t P, const float* xyz, int64_t* codes, int64_t* ord
     return C3DGS_OK;
 }
 
+int c3dgs_abs_accumulate(int64_t n, const float* g, float* acc, void* stream)
+{
+    if (n < 0 || (n > 0 && (!g || !acc))) return fail(C3DGS_E_INVALID, "abs_accumulate: bad arguments");
+    launch_abs_accumulate(n, g, acc, (hipStream_t)stream);
+    C3DGS_STAGE("abs_accumulate", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
 int c3dgs_adam_step(int32_t n_tensors, const c3dgs_adam_tensor* tensors, double beta1, double beta2, double eps, void* stream)
 {
     if (n_tensors < 0 || n_tensors > C3DGS_ADAM_MAX_TENSORS) return fail(C3DGS_E_INVALID, "adam_step: between 0 and 16 tensors per call");

@@ -617,7 +617,7 @@ class GaussianModel:
 
     # ---- render (gaussian_model.py:766-886)
     def render(self, viewpoint_camera, pipe, bg_color, scaling_modifier=1.0, override_color=None, clamp_color=True,
-               cov3d=None):
+               cov3d=None, gather_visible=True):
         if pipe.convert_SHs_python and override_color is None:
             raise NotImplementedError("convert_SHs_python: SH evaluation in Python is outside the mirrored render path")
         dev = self.device
@@ -631,7 +631,8 @@ class GaussianModel:
         screenspace_points = torch.zeros(self._xyz.shape, dtype=torch.float32, device=dev, requires_grad=True)
         if fused:
             return self._render_indexed_fused(settings, screenspace_points)
-        return self._render_composed(settings, screenspace_points, indexed, pipe, scaling_modifier, override_color, cov3d)
+        return self._render_composed(settings, screenspace_points, indexed, pipe, scaling_modifier, override_color, cov3d,
+                                     gather_visible)
 
     def _visible(self, settings):
         """visible flags, their exclusive scan and a deferred host read of the count."""
@@ -674,8 +675,12 @@ class GaussianModel:
         return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
                 "visible": visible.bool()}
 
-    def _render_composed(self, settings, screenspace_points, indexed, pipe, scaling_modifier, override_color, cov3d):
-        """Every other configuration of render(): the same getters, composed with torch gathers like the reference."""
+    def _render_composed(self, settings, screenspace_points, indexed, pipe, scaling_modifier, override_color, cov3d,
+                         gather_visible=True):
+        """Every other configuration of render(): the same getters, composed with torch gathers like the reference.
+        gather_visible=False (the sensitivity pass) hands all rows to the rasterizer instead of the reference's `t[visible]`
+        copies: the rasterizer culls the same Gaussians itself (mark_visible is its own frustum test), so image and gradients
+        are the same, `radii` / `viewspace_points` are then indexed by Gaussian rather than by visible row."""
         means3D = self.get_xyz
         opacity = self.get_opacity
         rasterizer = GaussianRasterizerIndexed(raster_settings=settings, optimize_camera=True) if indexed \
@@ -698,8 +703,11 @@ class GaussianModel:
         # `t[visible]` of the reference (gaussian_model.py:851-862) for every input, from ONE nonzero: a boolean-mask index
         # runs nonzero (with its host sync) per tensor, and its backward is a sort-based index_put(accumulate) -- 2 ms
         # per tensor for 6M rows -- although the rows are unique.
-        rows = visible.nonzero(as_tuple=False).squeeze(1)
-        pick = lambda t: None if t is None else (_MaskGather.apply(t, rows) if t.requires_grad else t.index_select(0, rows))  # noqa: E731
+        if gather_visible:
+            rows = visible.nonzero(as_tuple=False).squeeze(1)
+            pick = lambda t: None if t is None else (_MaskGather.apply(t, rows) if t.requires_grad else t.index_select(0, rows))  # noqa: E731
+        else:
+            pick = lambda t: t  # noqa: E731
         if indexed:
             image, radii = rasterizer(means3D=pick(means3D), means2D=pick(screenspace_points), shs=shs,
                                       sh_indices=pick(self._feature_indices), g_indices=pick(self._gaussian_indices),

@@ -17,6 +17,19 @@ from . import loss as _loss
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
+def _abs_accumulate(acc: torch.Tensor, grad: torch.Tensor) -> None:
+    """acc += |grad| (compress.py:110-113). On the GPU one launch of the library (one pass over grad, one read-modify-write of
+    acc); tensors that are not on a GPU (the gloo tests of the sharding logic inject their own compute) take the torch form."""
+    if acc.is_cuda and grad.is_cuda and acc.is_contiguous() and acc.dtype == torch.float32 and grad.dtype == torch.float32:
+        from . import _lib
+        g = grad.contiguous()
+        with torch.cuda.device(acc.device):
+            _lib.check(_lib.lib().c3dgs_abs_accumulate(acc.numel(), g.data_ptr(), acc.data_ptr(),
+                                                      torch.cuda.current_stream(acc.device).cuda_stream))
+    else:
+        acc += torch.abs(grad)
+
+
 def _dist(group):
     import torch.distributed as dist
     if group is None or not dist.is_available() or not dist.is_initialized():
@@ -68,9 +81,9 @@ def calc_importance(render_fn: Callable, features_dc: torch.Tensor, features_res
         else:
             gt_image = camera.original_image.to(image.device)
             loss_fn(image, gt_image).backward()                      # compress.py:105-109
-        accum1 += torch.abs(features_dc.grad)
-        accum2 += torch.abs(features_rest.grad)
-        accum3 += torch.abs(cov3d.grad)
+        _abs_accumulate(accum1, features_dc.grad)
+        _abs_accumulate(accum2, features_rest.grad)
+        _abs_accumulate(accum3, cov3d.grad)
         num_pixels += image.shape[1] * image.shape[2]
     if world > 1:
         npx = torch.tensor([float(num_pixels)], dtype=torch.float64, device=accum1.device)
@@ -91,7 +104,11 @@ def calc_importance_experimental(gaussians, cameras: Iterable, pipeline_params, 
     background = torch.zeros(3, dtype=torch.float32, device=cov3d.device)
 
     def render_fn(camera):
-        return gaussians.render(camera, pipeline_params, background, clamp_color=False, cov3d=cov3d * coeff)["render"]
+        # gather_visible=False: every row goes to the rasterizer, which culls what lies outside the frustum itself -- the
+        # reference's `t[visible]` copies (gaussian_model.py:851-862) and their scatter in the backward are ~4 GB of traffic
+        # per camera at 6M Gaussians for identical gradients (rows outside the frustum get zeros either way)
+        return gaussians.render(camera, pipeline_params, background, clamp_color=False, cov3d=cov3d * coeff,
+                                gather_visible=False)["render"]
 
     return calc_importance(render_fn, gaussians._features_dc, gaussians._features_rest, cov3d, cameras, use_gt=use_gt,
                            group=group)

@@ -222,6 +222,9 @@ typedef struct c3dgs_adam_tensor {
 } c3dgs_adam_tensor;
 int c3dgs_adam_step(int32_t n_tensors, const c3dgs_adam_tensor* tensors /*host*/, double beta1, double beta2, double eps, void* stream);
 
+/* ---- sensitivity pass (compress.py:110-113): acc[i] += |g[i]| for n floats, one launch */
+int c3dgs_abs_accumulate(int64_t n, const float* g, float* acc, void* stream);
+
 /* ---- extract_rot_scale(to_full_cov(cov)) (utils/splats.py:7-35; compress_covariance, compression/vq.py:186):
  * cov6[n,6] = upper triangle (xx,xy,xz,yy,yz,zz) -> rot[n,4] unit quaternion (r,x,y,z) of the eigenvector frame with
  * determinant +1, scale[n,3] = sqrt of the ascending eigenvalues of cov + 1e-8 I (NaN -> 1e-6). */

@@ -244,6 +244,44 @@ def test_non_indexed_render_and_python_covariance_paths_run():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
 
 
+def test_sensitivity_pass_without_row_gathers_equals_the_gathered_one():
+    """calc_importance_experimental hands all rows to the rasterizer (gather_visible=False) instead of the reference's
+    `t[visible]` copies: same importances (the rasterizer culls the rows behind the camera itself), and the accumulation
+    `acc += |g|` runs in the library's single-pass kernel. Checked against the gathered composition with torch's abs / add."""
+    from c3dgs_amd import sensitivity
+    from c3dgs_amd.model import GaussianModel, PipelineParams
+    W, H = 320, 200
+    sc = synth.scene(6000, W=W, H=H, focal=300.0, seed=5, scale_median=0.02, behind_fraction=0.3)
+    op = sc["opacities"].clamp(1e-6, 1 - 1e-6)
+    m = GaussianModel(3, quantization=False, device=DEV)
+    m.set_tensors(xyz=sc["means3D"], features_dc=sc["shs"][:, :1], features_rest=sc["shs"][:, 1:],
+                  scaling=sc["scales"] / sc["scales"].norm(dim=1, keepdim=True), rotation=sc["rotations"],
+                  opacity=torch.log(op / (1 - op)), scaling_factor=torch.log(sc["scales"].norm(dim=1, keepdim=True)))
+    cams = []
+    for yaw in (-0.2, 0.0, 0.25):
+        intr, ev = synth.camera(W, H, 300.0)
+        ev = ev.clone(); ev[1] = float(np.sin(0.5 * yaw)); ev[3] = float(np.cos(0.5 * yaw))
+        cams.append(_Cam(intr, ev))
+    pipe = PipelineParams()
+    imp, cg = sensitivity.calc_importance_experimental(m, cams, pipe, use_gt=False)
+    # the gathered composition, accumulated with torch
+    cov3d_scaled = m.get_covariance().detach()
+    coeff = m.get_scaling_factor.detach().square()
+    cov3d = (cov3d_scaled / coeff).requires_grad_(True)
+    bg = torch.zeros(3, device=DEV)
+    a1, a2, a3 = torch.zeros_like(m._features_dc), torch.zeros_like(m._features_rest), torch.zeros_like(cov3d)
+    for c in cams:
+        for t in (m._features_dc, m._features_rest, cov3d):
+            t.grad = None
+        m.render(c, pipe, bg, clamp_color=False, cov3d=cov3d * coeff)["render"].sum().backward()
+        a1 += m._features_dc.grad.abs(); a2 += m._features_rest.grad.abs(); a3 += cov3d.grad.abs()
+    npx = len(cams) * W * H
+    want_imp = torch.cat([a1, a2], 1).flatten(-2) / npx
+    assert float(imp.abs().max()) > 0 and float(cg.abs().max()) > 0
+    torch.testing.assert_close(imp, want_imp, rtol=1e-5, atol=1e-7 * float(want_imp.abs().max()))
+    torch.testing.assert_close(cg, a3 / npx, rtol=1e-5, atol=1e-7 * float((a3 / npx).abs().max()))
+
+
 def test_cpu_tensor_is_rejected_loudly():
     from c3dgs_amd.model import FakeQuantize
     with pytest.raises(RuntimeError, match="no CPU path"):
