@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define C3DGS_ABI_VERSION 2
+#define C3DGS_ABI_VERSION 3
 
 enum {
     C3DGS_OK = 0,

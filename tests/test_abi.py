@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/c3dgs_hip.h but not exported"
         assert s in _lib.PROTOTYPES, f"{s} has no ctypes prototype"
-    assert L.c3dgs_abi_version() == 2
+    assert L.c3dgs_abi_version() == 3
 
 
 def test_layouts_are_consistent(L):
