@@ -849,12 +849,14 @@ static void launch_wd_mfma(int64_t N, int C, const float* coefs, const int64_t* 
         const unsigned gl = (unsigned)std::min<int64_t>(1024, ((int64_t)flag_cap + WD_FB - 1) / WD_FB);
         wd_fixup_list_kernel<K><<<gl, 256, 0, s>>>(C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
     }
-    wd_fixup_kernel<K><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);   // whatever is still flagged
+    // whatever is still flagged: only possible when the list could not hold every point
+    if (!listed || (int64_t)flag_cap < N) wd_fixup_kernel<K><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
 }
 
 size_t wd_ws_bytes(int64_t N, int C, int K)
 {
-    const size_t list = ((size_t)(N > 0 ? N : 0) / 8 + 2) * sizeof(int);           // ~1-2 % of the points are ambiguous
+    const size_t list = ((size_t)(N > 0 ? N : 0) + 4) * sizeof(int);               // ~1-2 % of the points are ambiguous, but a list that
+                                                                                    // can hold them all saves the closing sweep's launch
     return ((K == 48 || K == 12 || K == 6) ? wd_split_bytes(C, K) : 0) + list;
 }
 
