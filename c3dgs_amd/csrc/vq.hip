@@ -517,10 +517,11 @@ wd_f16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* 
     top2_update(P0[r_], (uint32_t)(r_), keep_mask, best[0], second[0]);                                                   \
     top2_update(P1[r_], (uint32_t)(r_), keep_mask, best[1], second[1]);
     // rows past C hold zeros with a norm of 3e38 (wd_split_codebook_kernel): they lose against every real codeword, so the
-    // last tile needs no special case; the pipeline starts on a sub-tile's worth of such scores
+    // last tile needs no special case. The pipeline starts on a sub-tile's worth of FLT_MAX scores, which cannot displace
+    // the start value of `best` (so a point whose real scores are all NaN keeps group 0, row 0 = codeword 0).
     f32x16 pa0, pa1, pb0, pb1;
 #pragma unroll
-    for (int r = 0; r < 16; r++) { pb0[r] = 3.0e38f; pb1[r] = 3.0e38f; }
+    for (int r = 0; r < 16; r++) { pb0[r] = FLT_MAX; pb1[r] = FLT_MAX; }
     for (int tile = 0; tile < ntiles; tile++) {
         const int buf = tile & 1;
         if (tile + 1 < ntiles) C3DGS_HF_STAGE(tile + 1, buf ^ 1);   // in flight behind this tile's MFMAs; the buffer was last read before the previous barrier
@@ -599,7 +600,7 @@ wd_f16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* 
                 grp[1] = best[1] < was1_ ? (gid_prev_) : grp[1];                                                          \
             }
             const int g0 = tile * (MF_CT / 32);
-            C3DGS_HF_STEP(pa0, pa1, pb0, pb1, 0, g0 - 1);   // g0 - 1 = -1 on the first tile: those scores never win
+            C3DGS_HF_STEP(pa0, pa1, pb0, pb1, 0, g0 - 1);   // g0 - 1 = -1 on the first tile: FLT_MAX scores, never taken
             C3DGS_HF_STEP(pb0, pb1, pa0, pa1, 1, g0 + 0);
             C3DGS_HF_STEP(pa0, pa1, pb0, pb1, 2, g0 + 1);
             C3DGS_HF_STEP(pb0, pb1, pa0, pa1, 3, g0 + 2);
@@ -644,6 +645,7 @@ wd_f16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* 
             const float db = nb + xnorm[g], ds = ns + xnorm[g];
             const float margin = margin_rel * (fabsf(db) + fabsf(ds) + 2.0f * xnorm[g]) + 1e-37f;
             const bool ambiguous = !(ns - nb > margin);
+            ni = min(max(ni, 0), C - 1);                   // a padded row can only come out of NaN / inf scores, which are re-scanned anyway
             const float* x = coefs + rows[g] * MF_K;
             const float* cb = codebook + (size_t)ni * MF_K;
             float r = 0.f;

@@ -226,6 +226,16 @@ def test_weighted_distance_nan_rows_fall_back_to_codeword_zero(hip):
     ok = torch.ones(300, dtype=torch.bool); ok[7] = ok[200] = False
     d2, i2 = hip.weightedDistance(x[ok].cuda(), cb.cuda())
     assert torch.equal(i[ok.cuda()], i2) and torch.equal(d[ok.cuda()], d2)
+    # the same through the large-N form of the search (one 64-point set per wave, pipelined), ragged last codebook tile
+    g = torch.Generator().manual_seed(10)
+    xb = (torch.randn(70000, 48, generator=g) * 0.1).float()
+    cbb = (torch.randn(300, 48, generator=g) * 0.1).float()
+    xb[12345] = float("nan"); xb[69999, 47] = float("nan"); xb[64] = float("inf")
+    db, ib = hip.weightedDistance(xb.cuda(), cbb.cuda())
+    assert int(ib[12345]) == 0 and int(ib[69999]) == 0 and int(ib[64]) == 0 and 0 <= int(ib.min()) and int(ib.max()) < 300
+    okb = torch.ones(70000, dtype=torch.bool); okb[12345] = okb[69999] = okb[64] = False
+    d3, i3 = hip.weightedDistance(xb[okb].cuda(), cbb.cuda())
+    assert torch.equal(ib[okb.cuda()], i3) and torch.equal(db[okb.cuda()], d3)
 
 
 def test_split_scores_within_margin(hip):
