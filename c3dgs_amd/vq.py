@@ -191,6 +191,18 @@ _MT_WORDS, _MT_LEFT, _MT_NEXT, _MT_STATE, _MT_BYTES = 624, 2, 2, 3, 5056
 _FAST_DRAWS = True      # False: every batch through torch.randint itself (what the tests compare the fast path with)
 
 
+_RING_CACHE = {}            # (device, batch size) -> list of idle pinned rings
+_FILL_POOL = None
+
+
+def _fill_pool():
+    """One worker thread per process for the draws of the next batch (created on first use)."""
+    global _FILL_POOL
+    if _FILL_POOL is None:
+        _FILL_POOL = _futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="c3dgs-draws")
+    return _FILL_POOL
+
+
 class _BatchDraws:
     """The batch indices of one Lloyd step: exactly the reference's draws, `torch.randint(0, N, [chunk])` on the CPU
     default generator (vq.py:69), i.e. `mt19937() % N` per element. torch's scalar path costs ~2 ns per draw (2 ms for a
@@ -217,7 +229,13 @@ class _BatchDraws:
         self._st = st
         self.key = w[_MT_STATE:_MT_STATE + _MT_WORDS].to(torch.int32).contiguous()      # the words are < 2^32: keep the low halves
         self.left, self.next = C.c_int64(left), C.c_int64(nxt)
-        self.ring = [(torch.empty(chunk, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(self.RING)]
+        # the pinned ring is kept per (device, batch size) across calls: allocating (and later freeing) page-locked memory per
+        # call showed up as sporadic 50-80 ms stalls inside the Lloyd loop of a LATER call; a ring is checked out here and
+        # handed back by finish(), so two overlapping users never share one
+        self._ring_key = (str(device), int(chunk))
+        pool = _RING_CACHE.setdefault(self._ring_key, [])
+        self.ring = pool.pop() if pool else [(torch.empty(chunk, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+                                             for _ in range(self.RING)]
         self.k = 0
         # The fill of batch k + 1 (0.26 ms for 2^20 draws, sequential by nature) runs on ONE worker thread while the caller
         # queues the kernels of batch k: ctypes releases the GIL for the call, so the two really overlap (a covariance Lloyd
@@ -225,7 +243,7 @@ class _BatchDraws:
         # beyond `steps` batches and a batch drawn ahead of a loop that stops early is taken back by finish(), so the state
         # written back is exactly the reference's.
         self.steps = int(steps)
-        self._pool = _futures.ThreadPoolExecutor(max_workers=1) if self.steps > 1 else None
+        self._pool = _fill_pool() if self.steps > 1 else None
         self._pending = None
 
     def _fill(self, k, ahead=False):
@@ -266,9 +284,11 @@ class _BatchDraws:
             self._pending = None
             self.key, left, nxt = self._snap
             self.left, self.next = C.c_int64(left), C.c_int64(nxt)
-        if self._pool is not None:
-            self._pool.shutdown(wait=True)
-            self._pool = None
+        self._pool = None
+        for _, ev in self.ring:                          # the ring goes back once the last copies out of it are done
+            ev.synchronize()
+        _RING_CACHE.setdefault(self._ring_key, []).append(self.ring)
+        self.ring = None
         w = self._st.view(torch.int64)
         self._st.view(torch.int32)[_MT_LEFT] = self.left.value
         w[_MT_NEXT] = self.next.value
