@@ -29,6 +29,7 @@ Extra objects on the same JSON line:
                 glue + fused Adam next to the reference's torch glue + torch Adam); postvq_index_layout: the headline step with
                 the codebook indices laid out as compression/vq.py's join_features produces them
   device_allocs_in_timed_region   hipMalloc calls of torch's caching allocator during the K timed steps (expected 0)
+  host_gc_ms                      time Python's cyclic collector ran inside the timed region (expected ~0; see _quiesce)
 """
 import argparse
 import json
@@ -45,6 +46,28 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# Host-side hygiene of the timed regions: a full pass of Python's cyclic collector costs 30-50 ms in this process (torch's
+# object graph), i.e. more than a whole 20-step region; it fires after a fixed number of container allocations, wherever the
+# program happens to be. Each timed loop therefore starts from an emptied young generation (gc.collect() outside the timing,
+# the collector stays ENABLED) and reports the collector time that fell inside it (`host_gc_ms`), so a distorted line shows.
+_GC = {"ms": 0.0, "t": 0.0}
+
+
+def _gc_cb(phase, info):
+    if phase == "start":
+        _GC["t"] = time.perf_counter()
+    else:
+        _GC["ms"] += (time.perf_counter() - _GC["t"]) * 1e3
+
+
+def _quiesce():
+    import gc
+    if _gc_cb not in gc.callbacks:
+        gc.callbacks.append(_gc_cb)
+    gc.collect()
+    return _GC["ms"]
+
+
 MFMA_F32_PEAK_TFLOPS = 157.3   # f32-in MFMA dense peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md, Matrix cores)
 
@@ -240,11 +263,13 @@ def main():
     _lib.profile_enable(True, only=dom)
     _lib.profile_read()
     n_alloc = torch.cuda.memory_stats(dev)["num_device_alloc"]
+    gc_ms = _quiesce()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc_ms = _GC["ms"] - gc_ms
     n_alloc = torch.cuda.memory_stats(dev)["num_device_alloc"] - n_alloc
     dom_live = _lib.profile_read()
     _lib.profile_enable(False)
@@ -328,6 +353,7 @@ def main():
         # informational: kernels of one step (untimed profiling pass) vs the timed step. A ratio far above 1 means the
         # GPU sat idle waiting for the host during the timed region (seen once on a heavily loaded box: profiles/README.md)
         "device_allocs_in_timed_region": n_alloc,     # hipMalloc calls of the caching allocator (expected: 0)
+        "host_gc_ms": round(gc_ms, 3),                # time of Python's cyclic collector inside the timed region (expected: ~0)
         "step_over_kernel_time": (1e3 * elapsed / args.steps) / max(sum(v for k, v in stage_ms.items() if k in raster_names), 1e-9),
         "view_alg_bytes": view_bytes,
         "view_hbm_frac": view_bytes * (args.steps / elapsed) / 1e9 / HBM_PEAK_GBS,
@@ -354,6 +380,7 @@ def main():
         for _ in range(3):
             qat_step()
         barrier()
+        _quiesce()
         tq = time.perf_counter()
         for _ in range(args.steps):
             qat_step()
@@ -467,11 +494,13 @@ def bench_postvq_layout(step, t, P, steps, dev, _lib):
                 break
             prev = cur
         n_alloc = torch.cuda.memory_stats(dev)["num_device_alloc"]
+        gc_ms = _quiesce()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        gc_ms = _GC["ms"] - gc_ms
         n_alloc = torch.cuda.memory_stats(dev)["num_device_alloc"] - n_alloc
         _lib.profile_enable(True)
         _lib.profile_read()
@@ -483,7 +512,7 @@ def bench_postvq_layout(step, t, P, steps, dev, _lib):
     finally:
         t["sh_indices"], t["g_indices"] = saved
     return {"metric": "views/s fwd+bwd, indices as join_features lays them out", "value": steps / el, "ms_per_step": 1e3 * el / steps,
-            "device_allocs_in_timed_loop": n_alloc,
+            "device_allocs_in_timed_loop": n_alloc, "host_gc_ms": round(gc_ms, 3),
             "stages_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(st.items(), key=lambda kv: -kv[1][0])[:6]}}
 
 
@@ -559,12 +588,13 @@ def bench_qat_model(c3dgs_amd, _lib, dev, ix_cpu, intr, evd, W, H, steps, barrie
         for _ in range(4):
             fn()
         barrier()
+        gc_ms = _quiesce()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        res[name] = {"views_per_s": world * steps / el, "ms_per_view": 1e3 * el / steps}
+        res[name] = {"views_per_s": world * steps / el, "ms_per_view": 1e3 * el / steps, "host_gc_ms": round(_GC["ms"] - gc_ms, 3)}
     _lib.profile_enable(True)                                  # separate, untimed pass for the glue kernels' durations
     _lib.profile_read()
     for _ in range(5):
@@ -614,6 +644,7 @@ def bench_vq(c3dgs_amd, _lib, dev, rank, world, steps, cpu_baseline):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    _quiesce()
     st = run(steps)                                           # timed: lloyd_seconds brackets exactly `steps` Lloyd steps
     el = torch.tensor([st["lloyd_seconds"], st["final_assignment_seconds"]], dtype=torch.float64, device=dev)
     if world > 1:
