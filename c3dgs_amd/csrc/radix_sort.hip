@@ -76,9 +76,16 @@ static OsPlan os_plan(int total_bits)
 }
 
 template <class K> static size_t os_blocks(size_t n) { return (n + OsShape<K>::TILE - 1) / OsShape<K>::TILE; }
+// The tile-key sort (u16 keys, two passes) runs its FIRST pass without the chained look-back: the histogram kernel works tile by
+// tile and leaves every tile's digit counts in a table, one small kernel turns the table's columns into exclusive prefixes
+// over the tiles (and their totals into the global histograms), and the pass reads its offsets from there. Measured on the
+// 16.4 M pairs of the bench view: the look-back costs ~30 us per pass at 2002 tiles (tools/time_sort.py knock-out).
+template <class K> constexpr bool os_pre_pass0() { return sizeof(K) == 2; }
+constexpr int OS_TABLE_ROW = 2 * OS_RADIX;          // table columns: [pass 0 digits | pass 1 digits], each over all tiles
+template <class K> static size_t os_table_words(size_t n) { return os_pre_pass0<K>() ? os_blocks<K>(n) * OS_TABLE_ROW : 0; }
 template <class K> static size_t os_ctrl_bytes(size_t n, int passes)
 {
-    return align_up(((size_t)passes * OS_RADIX + (size_t)passes * os_blocks<K>(n) * OS_RADIX + 64) * sizeof(uint32_t));
+    return align_up(((size_t)passes * OS_RADIX + (size_t)passes * os_blocks<K>(n) * OS_RADIX + 64 + os_table_words<K>(n)) * sizeof(uint32_t));
 }
 
 // all digit histograms in one read of the keys: 1024-thread workgroups (at most 512 of them, so the final flush stays a
@@ -123,10 +130,70 @@ __global__ void __launch_bounds__(OS_HIST_BLOCK) os_hist_kernel(const K* __restr
     }
 }
 
+// tile-by-tile histograms of the u16 sort: workgroup b counts the digits of tile b (the pass kernel's tile b) for the first
+// two passes and stores them as row b of the table -- plain stores, no global atomics (the closing atomics of os_hist_kernel
+// are what makes it slower with more workgroups)
+__global__ void __launch_bounds__(1024) os_tile_hist_kernel(const uint16_t* __restrict__ keys, uint32_t n, OsPlan plan, uint32_t* __restrict__ table)
+{
+    constexpr int TILE = OsShape<uint16_t>::TILE;
+    static_assert(TILE == 8 * 1024, "one 16-byte load of 8 keys per thread");
+    __shared__ uint32_t s_h[OS_TABLE_ROW];
+    if (threadIdx.x < OS_TABLE_ROW) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (uint32_t)TILE + threadIdx.x * 8u;
+    const uint32_t m0 = (1u << plan.bits[0]) - 1u, m1 = plan.passes > 1 ? (1u << plan.bits[1]) - 1u : 0u;
+    auto add = [&](uint32_t k) {
+        atomicAdd(&s_h[k & m0], 1u);
+        if (plan.passes > 1) atomicAdd(&s_h[OS_RADIX + ((k >> plan.bits[0]) & m1)], 1u);
+    };
+    if (base + 8 <= n && (reinterpret_cast<uintptr_t>(keys) & 15u) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4*>(keys + base);
+        const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int e = 0; e < 4; e++) { add(w[e] & 0xffffu); add(w[e] >> 16); }
+    } else {
+        for (uint32_t i = base; i < min(base + 8u, n); i++) add((uint32_t)keys[i]);
+    }
+    __syncthreads();
+    // column-major table (a column = one (pass, digit) over all tiles, contiguous for the scan); unused digit columns stay unwritten
+    const int t = threadIdx.x;
+    if (t < OS_TABLE_ROW && (t >> 8) < plan.passes && (t & (OS_RADIX - 1)) < (1 << plan.bits[(t >> 8) & 1]))
+        table[(size_t)t * gridDim.x + blockIdx.x] = s_h[t];
+}
+
+// one workgroup per USED table column (pass, digit): the column's total goes to the global histogram of that pass; the pass-0
+// columns are replaced by their exclusive prefixes over the tiles (what the look-back would have produced)
+__global__ void __launch_bounds__(256) os_table_scan_kernel(uint32_t* __restrict__ table, uint32_t blocks, OsPlan plan, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s_w[4];
+    const int n0 = 1 << plan.bits[0];
+    const int pass = (int)blockIdx.x < n0 ? 0 : 1, digit = (int)blockIdx.x - (pass ? n0 : 0), col = pass * OS_RADIX + digit;
+    uint32_t* column = table + (size_t)col * blocks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < blocks; b0 += 256) {                 // 256 tiles per sweep, coalesced
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t c = b < blocks ? column[b] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        __syncthreads();                                            // previous sweep's s_w has been read
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        uint32_t off = carry;
+        for (int w = 0; w < wave; w++) off += s_w[w];
+        if (pass == 0 && b < blocks) column[b] = off + incl - c;
+        carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    }
+    if (threadIdx.x == 0) hist[col] = carry;                        // hist is [pass][256]
+}
+
 __device__ __forceinline__ uint32_t os_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void os_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <class K, int BITS>
+// PRE: the tile's exclusive digit prefixes come from the table os_table_scan_kernel prepared (`status` = the table, no ticket,
+// no look-back); otherwise they are found by the chained look-back over the earlier tiles' status words.
+template <class K, int BITS, bool PRE>
 __global__ void __launch_bounds__(OsShape<K>::BLOCK)
 os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout,
                uint32_t n, int shift, const uint32_t* __restrict__ hist, uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
@@ -145,7 +212,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
     __shared__ uint32_t s_vals[OS_TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_bid = atomicAdd(ticket, 1u);
+    if (tid == 0) s_bid = PRE ? blockIdx.x : atomicAdd(ticket, 1u);
     for (int q = tid; q < OS_WAVES * OS_RADIX; q += OS_BLOCK) (&s_cnt[0][0])[q] = 0;
     __syncthreads();
     const uint32_t bid = s_bid;
@@ -204,7 +271,8 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
         s_start[tid] = start;
         // decoupled look-back over the earlier tiles for digit `tid`
         uint32_t* my = status + (size_t)bid * OS_RADIX + tid;
-        if (bid == 0) os_store(my, OS_FLAG_PRE | tot);
+        if (PRE) pre = tid < (1 << BITS) ? status[(size_t)tid * gridDim.x + bid] : 0u;   // column-major table, pass-0 columns
+        else if (bid == 0) os_store(my, OS_FLAG_PRE | tot);
         else {
             os_store(my, OS_FLAG_AGG | tot);
             for (int64_t b = (int64_t)bid - 1;; b--) {
@@ -257,15 +325,15 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
     }
 }
 
-template <class K>
+template <class K, bool PRE>
 static void os_launch_pass(int bits, unsigned blocks, hipStream_t s, const K* ki, K* ko, const uint32_t* vi, uint32_t* vo, uint32_t n,
                            int shift, const uint32_t* hist, uint32_t* status, uint32_t* ticket, const uint2* gsrc, uint2* gdst)
 {
-#define C3DGS_OS_CASE(B) case B: os_pass_kernel<K, B><<<blocks, OsShape<K>::BLOCK, 0, s>>>(ki, ko, vi, vo, n, shift, hist, status, ticket, gsrc, gdst); break
+#define C3DGS_OS_CASE(B) case B: os_pass_kernel<K, B, PRE><<<blocks, OsShape<K>::BLOCK, 0, s>>>(ki, ko, vi, vo, n, shift, hist, status, ticket, gsrc, gdst); break
     switch (bits) {
         C3DGS_OS_CASE(1); C3DGS_OS_CASE(2); C3DGS_OS_CASE(3); C3DGS_OS_CASE(4);
         C3DGS_OS_CASE(5); C3DGS_OS_CASE(6); C3DGS_OS_CASE(7);
-        default: os_pass_kernel<K, 8><<<blocks, OsShape<K>::BLOCK, 0, s>>>(ki, ko, vi, vo, n, shift, hist, status, ticket, gsrc, gdst); break;
+        default: os_pass_kernel<K, 8, PRE><<<blocks, OsShape<K>::BLOCK, 0, s>>>(ki, ko, vi, vo, n, shift, hist, status, ticket, gsrc, gdst); break;
     }
 #undef C3DGS_OS_CASE
 }
@@ -294,16 +362,24 @@ static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, 
     uint32_t* hist = (uint32_t*)base;
     uint32_t* status = hist + (size_t)plan.passes * OS_RADIX;
     uint32_t* ticket = status + (size_t)plan.passes * blocks * OS_RADIX;
+    uint32_t* table = ticket + 64;                                  // [OS_TABLE_ROW columns][blocks], u16 sort only
+    constexpr bool pre0 = os_pre_pass0<K>();
     K* tk[2]; uint32_t* tv[2];
     char* q = base + ctrl;
     for (int i = 0; i < 2; i++) { tk[i] = (K*)q; q += align_up(n * sizeof(K)); tv[i] = (uint32_t*)q; q += align_up(n * sizeof(uint32_t)); }
-    hipError_t e = hipMemsetAsync(base, 0, ctrl, s);
+    // the table is written in full by os_tile_hist_kernel: only the words in front of it need clearing
+    hipError_t e = hipMemsetAsync(base, 0, pre0 ? (size_t)((char*)table - base) : ctrl, s);
     if (e != hipSuccess) return e;
-    const size_t nvec16 = n * sizeof(K) / 16 + 1;
-    // 4 x 16 bytes per thread, at most 512 workgroups: measured optimum on both sorts (fewer workgroups: LDS-atomic bound;
-    // more: the closing global atomics, one per workgroup and non-empty bin on the same few hundred words, take over)
-    const unsigned hb = (unsigned)std::min<size_t>((nvec16 + OS_HIST_BLOCK * 4 - 1) / (OS_HIST_BLOCK * 4), 512);
-    os_hist_kernel<K><<<hb, OS_HIST_BLOCK, 0, s>>>(kin, n, plan, hist);
+    if constexpr (pre0) {
+        os_tile_hist_kernel<<<(unsigned)blocks, 1024, 0, s>>>((const uint16_t*)kin, (uint32_t)n, plan, table);
+        os_table_scan_kernel<<<(unsigned)((1 << plan.bits[0]) + (plan.passes > 1 ? (1 << plan.bits[1]) : 0)), 256, 0, s>>>(table, (uint32_t)blocks, plan, hist);
+    } else {
+        const size_t nvec16 = n * sizeof(K) / 16 + 1;
+        // 4 x 16 bytes per thread, at most 512 workgroups: measured optimum on both sorts (fewer workgroups: LDS-atomic bound;
+        // more: the closing global atomics, one per workgroup and non-empty bin on the same few hundred words, take over)
+        const unsigned hb = (unsigned)std::min<size_t>((nvec16 + OS_HIST_BLOCK * 4 - 1) / (OS_HIST_BLOCK * 4), 512);
+        os_hist_kernel<K><<<hb, OS_HIST_BLOCK, 0, s>>>(kin, n, plan, hist);
+    }
     int shift = 0;
     for (int p = 0; p < plan.passes; p++) {
         const K* ki = p == 0 ? kin : tk[(p - 1) & 1];
@@ -312,8 +388,12 @@ static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, 
         uint32_t* vo = p == plan.passes - 1 ? vout : tv[p & 1];
         const bool last = p == plan.passes - 1;
         // ticket + p is this pass's counter
-        os_launch_pass<K>(plan.bits[p], (unsigned)blocks, s, ki, ko, vi, vo, (uint32_t)n, shift, hist + (size_t)p * OS_RADIX,
-                          status + (size_t)p * blocks * OS_RADIX, ticket + p, last ? gather_src : nullptr, last ? gather_dst : nullptr);
+        if (pre0 && p == 0)
+            os_launch_pass<K, true>(plan.bits[p], (unsigned)blocks, s, ki, ko, vi, vo, (uint32_t)n, shift, hist, table, ticket,
+                                    last ? gather_src : nullptr, last ? gather_dst : nullptr);
+        else
+            os_launch_pass<K, false>(plan.bits[p], (unsigned)blocks, s, ki, ko, vi, vo, (uint32_t)n, shift, hist + (size_t)p * OS_RADIX,
+                                     status + (size_t)p * blocks * OS_RADIX, ticket + p, last ? gather_src : nullptr, last ? gather_dst : nullptr);
         shift += plan.bits[p];
     }
     return hipGetLastError();

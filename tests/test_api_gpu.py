@@ -266,3 +266,20 @@ def test_intrinsic_written_through_data_is_noticed(hip):
     assert c1.shape == (3, 160, 256)
     fresh = _render_indexed(hip, _settings(hip, intr2.cuda(), ev), ix, evd)[0]
     assert torch.equal(c1, fresh)
+
+
+def test_abs_accumulate_entry_point(hip):
+    """c3dgs_abs_accumulate (the sensitivity pass's acc += |g|): sizes that are not multiples of 4, unaligned views, n = 0."""
+    import torch
+    from c3dgs_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(4)
+    for n, off in [(1, 0), (7, 0), (1000003, 0), (4096, 1), (4099, 3), (0, 0)]:
+        a = torch.randn(n + off, generator=g).cuda()
+        acc = torch.rand(n + off, generator=g).cuda()
+        want = acc.clone()
+        want[off:] += a[off:].abs()
+        _lib.check(L.c3dgs_abs_accumulate(n, a[off:].data_ptr() if n else None, acc[off:].data_ptr() if n else None, None))
+        torch.cuda.synchronize()
+        assert torch.equal(acc, want), (n, off)
+    assert L.c3dgs_abs_accumulate(5, None, None, None) == 1
