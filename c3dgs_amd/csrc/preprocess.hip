@@ -392,6 +392,7 @@ duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint
     __shared__ uint32_t s_end[256];      // inclusive emission offset of each of the block's Gaussians
     __shared__ uint32_t s_id[256];
     __shared__ uint2 s_rect[256];
+    __shared__ uint32_t s_inv[256];      // ceil(2^32 / rectangle width): one division per Gaussian instead of one per instance
     __shared__ uint32_t s_wsum[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int k0 = blockIdx.x * 256, k = k0 + t;
@@ -402,6 +403,8 @@ duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint
         incl = rect_tiles(rc);
         s_id[t] = order[k];
         s_rect[t] = rc;
+        const uint32_t w = (rc.y & 0xffff) - (rc.x & 0xffff);
+        s_inv[t] = w > 1 ? 0xffffffffu / w + 1u : 0u;         // width 1: quotient = local (handled below); width 0: no instances
     }
     // depth-order scan inside the workgroup (the workgroup bases come from scan_blocks_kernel)
 #pragma unroll
@@ -414,19 +417,65 @@ duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint
     __syncthreads();
     const int nk = min(256, P - k0);
     const uint32_t out_end = s_end[nk - 1];
-    for (uint32_t o = out_begin + t; o < out_end; o += 256) {
-        int lo = 0, hi = nk - 1;                  // first Gaussian whose inclusive end is > o
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_end[mid] > o) hi = mid; else lo = mid + 1;
+    // Owner of every output position WITHOUT a search: each Gaussian with instances drops its number at the position where its
+    // run starts (`heads`), and a prefix maximum along the positions spreads it over the run (the numbers grow with the
+    // position). A chunk is 1024 positions, four consecutive ones per lane, aligned to 4 so that the four 16-bit keys and the
+    // four ids leave as one 8-byte and one 16-byte store. (A binary search per instance in the 256 run ends cost ~48 of this
+    // kernel's ~70 instructions per instance: 0.050 -> 0.032 ms on the bench view.)
+    constexpr int CH = 1024;
+    __shared__ uint16_t s_head[CH];
+    __shared__ uint32_t s_wmax[4];
+    const uint32_t my_tiles = k < P ? rect_tiles(s_rect[t]) : 0u;
+    const uint32_t my_begin = s_end[t] - my_tiles;
+    uint32_t carry = 0;                                              // owner + 1 of the position in front of the chunk
+    for (uint32_t c0 = out_begin & ~3u; c0 < out_end; c0 += CH) {
+        reinterpret_cast<uint2*>(s_head)[t] = make_uint2(0u, 0u);
+        __syncthreads();
+        if (my_tiles && my_begin >= c0 && my_begin < c0 + CH) s_head[my_begin - c0] = (uint16_t)(t + 1);
+        __syncthreads();
+        const uint2 hv = reinterpret_cast<const uint2*>(s_head)[t];
+        uint32_t m[4] = { hv.x & 0xffffu, hv.x >> 16, hv.y & 0xffffu, hv.y >> 16 };
+        m[1] = max(m[0], m[1]); m[2] = max(m[1], m[2]); m[3] = max(m[2], m[3]);
+        uint32_t scan = m[3];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(scan, o); if (lane >= o) scan = max(scan, v); }
+        uint32_t before = __shfl_up(scan, 1);
+        if (lane == 0) before = 0;
+        if (lane == 63) s_wmax[wave] = scan;
+        __syncthreads();
+        before = max(before, carry);
+        for (int w = 0; w < wave; w++) before = max(before, s_wmax[w]);
+        carry = max(max(carry, max(s_wmax[0], s_wmax[1])), max(s_wmax[2], s_wmax[3]));
+        const uint32_t o0 = c0 + 4u * t;
+        uint16_t kq[4];
+        uint32_t vq[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t o = o0 + e;
+            const uint32_t own = max(before, m[e]);                 // 0 only in front of out_begin
+            kq[e] = 0; vq[e] = 0;
+            if (o >= out_begin && o < out_end) {
+                const int g = (int)own - 1;
+                const uint32_t first = (g == 0) ? out_begin : s_end[g - 1];
+                const uint2 rc = s_rect[g];
+                const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
+                const uint32_t local = o - first, w = (uint32_t)(x1 - x0), inv = s_inv[g];
+                // local / w as a multiply-high by ceil(2^32 / w): exact while local * w < 2^32, and local < rectangle area <=
+                // number of tiles <= 2^16 (tile keys are 16 bits), w < 2^16
+                const uint32_t ry = inv ? __umulhi(local, inv) : local, rx = local - ry * w;   // emission order: y outer, x inner (:98-108)
+                kq[e] = (uint16_t)((y0 + ry) * grid_x + (x0 + rx));
+                vq[e] = s_id[g];
+            }
         }
-        const uint32_t first = (lo == 0) ? out_begin : s_end[lo - 1];
-        const uint2 rc = s_rect[lo];
-        const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
-        const uint32_t local = o - first, w = (uint32_t)(x1 - x0);
-        const uint32_t ry = local / w, rx = local - ry * w;       // emission order: y outer, x inner (:98-108)
-        keys[o] = (uint16_t)((y0 + ry) * grid_x + (x0 + rx));
-        values[o] = s_id[lo];
+        if (o0 >= out_begin && o0 + 4 <= out_end) {
+            *reinterpret_cast<uint2*>(keys + o0) = make_uint2((uint32_t)kq[0] | ((uint32_t)kq[1] << 16), (uint32_t)kq[2] | ((uint32_t)kq[3] << 16));
+            *reinterpret_cast<uint4*>(values + o0) = make_uint4(vq[0], vq[1], vq[2], vq[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (o0 + e >= out_begin && o0 + e < out_end) { keys[o0 + e] = kq[e]; values[o0 + e] = vq[e]; }
+        }
+        __syncthreads();                                             // s_head / s_wmax are rewritten by the next chunk
     }
 }
 
