@@ -251,14 +251,17 @@ static int backward_impl(const c3dgs_raster_params* pp, bool indexed, const int3
     uint32_t* live_ids = tile_order + 65536;
     uint32_t* live_slots = live_ids + p256;
     uint32_t* live_count = live_slots + p256;
-    // one launch: tile schedule of the blend kernel + the flag clear + the codebook-gradient clear
+    // one launch: tile schedule of the blend kernel + the flag clear. The codebook-gradient clear (80 MB on the bench view, needed
+    // only by the per-Gaussian kernel's scatter-adds) rides in the blend kernel itself, a slice per tile workgroup: that kernel is
+    // bound by vector issue and leaves the memory system idle (without a blend launch the clear stays here)
     { StageTimer t_(ST_ZERO_PARTIALS, s);
-      launch_backward_prep(R > 0 ? W : 0, H, img, tile_order, touched, align_up(r1) / 16, cb_zero, cb_zero16, s); }
+      launch_backward_prep(R > 0 ? W : 0, H, img, tile_order, touched, align_up(r1) / 16, R > 0 ? nullptr : cb_zero,
+                           R > 0 ? 0 : cb_zero16, s); }
     if (R > 0) {
         const BinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), R, W, H);
         { StageTimer t_(ST_RENDER_BWD, s);
           launch_render_backward(W, H, img, b.point_list, g.splat, g.block_base, p.background, dL_dout_color, partials, touched,
-                                 (const uint8_t*)b.sort_temp, tile_order, s); } // K10
+                                 (const uint8_t*)b.sort_temp, tile_order, cb_zero, cb_zero16, s); } // K10
         C3DGS_STAGE("render_backward", p.debug, s);
     }
     { StageTimer t_(ST_BWD_PREPROCESS, s);

@@ -171,7 +171,8 @@ void launch_backward_prep(int W, int H, const ImgPtrs& img, uint32_t* tile_order
                           size_t n16_b, hipStream_t s);
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                             const uint32_t* block_base, const float* bg, const float* dL_dpix, float* partials,
-                            uint8_t* touched, const uint8_t* qmask, const uint32_t* tile_order, hipStream_t s);
+                            uint8_t* touched, const uint8_t* qmask, const uint32_t* tile_order, void* zero_span, size_t zero_n16,
+                            hipStream_t s);
 // backward_preprocess.hip
 void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* radii, const GeomPtrs& g,
                                 float* partials, const uint8_t* touched, uint32_t* live_count, uint32_t* live_ids,

@@ -387,8 +387,14 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                        const uint32_t* __restrict__ block_base, const float* __restrict__ bg, const float* __restrict__ final_Ts,
                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                        float* __restrict__ partials, uint8_t* __restrict__ touched, const uint8_t* __restrict__ qmask,
-                       const uint32_t* __restrict__ tile_order)
+                       const uint32_t* __restrict__ tile_order, uint4* __restrict__ zero_span, size_t zero_n16)
 {
+    // every workgroup of the grid first clears its slice of `zero_span` (the scatter-added codebook gradients of the indexed
+    // variant, which the NEXT kernel needs cleared): plain stores that cost this vector-issue-bound kernel nothing
+    if (zero_n16) {
+        const size_t per = (zero_n16 + gridDim.x - 1) / gridDim.x, z0 = (size_t)blockIdx.x * per, z1 = min(z0 + per, zero_n16);
+        for (size_t i = z0 + threadIdx.x; i < z1; i += 256) zero_span[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     // longest tiles first (tile_order: descending tile_used), so that the last workgroups to start are the short ones
     if ((int)blockIdx.x >= T) return;
     const int tile = (int)tile_order[blockIdx.x];
@@ -580,12 +586,14 @@ void launch_backward_prep(int W, int H, const ImgPtrs& img, uint32_t* tile_order
 
 void launch_render_backward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                             const uint32_t* block_base, const float* bg, const float* dL_dpix, float* partials,
-                            uint8_t* touched, const uint8_t* qmask, const uint32_t* tile_order, hipStream_t s)
+                            uint8_t* touched, const uint8_t* qmask, const uint32_t* tile_order, void* zero_span, size_t zero_n16,
+                            hipStream_t s)
 {
     const int gx = tiles_x(W), T = gx * tiles_y(H);
     const int grid = ((T + 7) / 8) * 8;
     render_backward_kernel<<<grid, 256, 0, s>>>(W, H, gx, T, img.ranges, img.tile_used, point_list, splat, block_base, bg, img.final_T,
-                                                img.n_contrib, dL_dpix, partials, touched, qmask, tile_order);
+                                                img.n_contrib, dL_dpix, partials, touched, qmask, tile_order, (uint4*)zero_span,
+                                                zero_span ? zero_n16 : 0);
 }
 
 } // namespace c3dgs
