@@ -741,12 +741,14 @@ def cpu_baseline_and_parity(ix_cpu, intr, ev, W, H, focal):
     try:
         parity = fullsize.compare(inp, cam, True, st, ref, dL)
         parity["sample"] = f"HIP (C-ABI front-end) vs oracle, the first {n_used} of {P} Gaussians of the timed workload, fwd+bwd"
-        parity["bars"] = "integers equal; PSNR >= 80 dB; dPSNR <= 0.05 dB; grad rel-inf <= 1e-4 away from flipped pixels, <= 1e-3 overall"
+        parity["bars"] = ("integers equal; PSNR >= 80 dB; dPSNR <= 0.05 dB; grad rel-inf <= 1e-4 away from flipped pixels, <= 1e-3 overall; "
+                          "every flipped pixel proven an fp32 borderline in float64 (flips_outside_band == 0)")
         parity["ok"] = bool(
             parity["num_rendered_equal"] and parity["image_finite"] and parity["psnr_db"] >= 80.0 and parity["delta_psnr_db"] <= 0.05
             and all(parity[k] == 0 for k in ("radii_mismatches", "tiles_touched_mismatches", "sorted_keys_mismatches",
                                              "point_list_mismatches", "ranges_mismatches", "splat_float_bit_mismatches"))
-            and parity["grad_rel_inf_excluding_flips_max"] <= 1e-4 and parity["grad_rel_inf_max"] <= 1e-3)
+            and parity["grad_rel_inf_excluding_flips_max"] <= 1e-4 and parity["grad_rel_inf_max"] <= 1e-3
+            and parity["flips_outside_band"] == 0)
     except Exception as e:
         parity = {"error": repr(e)}
     return base, parity

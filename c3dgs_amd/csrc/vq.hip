@@ -949,14 +949,18 @@ vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x
             // no two points of the chunk share a codeword (the steady state): nothing to merge, so the chunk's cnt * (D+1)
             // elements are added densely, 64 consecutive elements per instruction (every lane busy; a point's D+1 atomics
             // stay contiguous)
-            const int total = (int)__popcll(leaders) * D1;
+            const int cnt = (int)__popcll(leaders), total = cnt * D1;   // valid lanes are the first cnt lanes of the wave
             const uint32_t row_lo = (uint32_t)row, row_hi = (uint32_t)((uint64_t)row >> 32);
-            for (int e = lane; e < total; e += 64) {                 // the point's row / weight / codeword come from the lane
-                const int j = e / D1, c = e - j * D1;                // that already holds them (no dependent global loads)
+            // The trip count is WAVE-UNIFORM and the shuffles run with every lane active: ds_bpermute returns 0 from a source
+            // lane that is masked off, so a lane-dependent loop bound (lanes with e >= total leaving early in the last sweep)
+            // lost the contributions of points whose owner lane had left -- ragged tails with (cnt * D1) % 64 in 1..cnt-1.
+            for (int e0 = 0; e0 < total; e0 += 64) {                 // the point's row / weight / codeword come from the lane
+                const int e = e0 + lane;                             // that already holds them (no dependent global loads)
+                const int j = min(e / D1, cnt - 1), c = e - j * D1;
                 const int64_t rj = (int64_t)(((uint64_t)(uint32_t)__shfl((int)row_hi, j) << 32) | (uint32_t)__shfl((int)row_lo, j));
                 const float wj = __shfl(wn, j);
                 const uint32_t idj = (uint32_t)__shfl((int)id, j);
-                atomicAdd(S + (size_t)idj * D1 + c, c < D ? x[rj * D + c] * wj : wj);
+                if (e < total) atomicAdd(S + (size_t)idj * D1 + c, c < D ? x[rj * D + c] * wj : wj);
             }
             continue;
         }

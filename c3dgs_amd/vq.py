@@ -49,7 +49,7 @@ def weightedDistance(coefs: torch.Tensor, codebook: torch.Tensor, gather: Option
     idx = torch.zeros(N, dtype=torch.int64, device=x.device)
     if N > 0 and cb.size(0) > 0:
         with torch.cuda.device(x.device):
-            # scratch: the codebook split into bf16 pieces for the matrix cores + the list of ambiguous points (~1 %)
+            # scratch: the codebook split into two fp16 pieces for the matrix cores + the list of ambiguous points (~1 %)
             ws = torch.empty(int(L.c3dgs_weighted_distance_ws_bytes(N, int(cb.size(0)), int(x.size(1)))), dtype=torch.uint8,
                              device=x.device)
             rc = L.c3dgs_weighted_distance_ws(N, int(cb.size(0)), int(x.size(1)), x.data_ptr(),

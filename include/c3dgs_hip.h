@@ -139,18 +139,23 @@ int c3dgs_weighted_distance(int64_t N, int32_t C, int32_t K, const float* coefs,
                             const float* codebook, float* out_dist, int64_t* out_idx, void* stream);
 
 /* the same with device scratch `ws` (16-byte aligned, c3dgs_weighted_distance_ws_bytes(N, C, K) bytes; less is legal):
- *   [the codebook split into three bf16 pieces per value, laid out as matrix-core operand fragments][int32 list of the points
- *    whose two best candidates the fast search cannot tell apart].
- * With room for the split codebook (K = 48 or 12) the candidate search runs on the bf16 matrix cores with six piece products
- * per multiply (16x the fp32 matrix rate per product, ~2^-22 relative error per term); without, on the fp32 matrix cores.
- * Either way the winner's distance is recomputed with the reference's k-ordered chain and every point inside the error
- * margin is re-scanned exactly (listed points several per codebook pass): identical results, distances and indices. */
+ *   [the codebook scaled by one power of two per call and split into TWO fp16 pieces per value (v = h + l, h = fp16(v),
+ *    l = fp16(v - h): 22 significant bits), laid out as matrix-core operand fragments, + the scaled ||c||^2 and the call's
+ *    abs-max word][int32 list of the points whose two best candidates the fast search cannot tell apart].
+ * With room for the split codebook (K = 48, 12 or 6; C >= 32) the candidate search runs on the fp16 matrix cores
+ * (v_mfma_f32_32x32x16_f16) with THREE piece products per multiply (xh*ch + xh*cl + xl*ch; ~3 * 2^-22 relative error per
+ * term); without, on the fp32 matrix cores. The scale puts the codebook's largest magnitude into [2^10, 2^11); whatever
+ * leaves fp16's range after scaling (points far beyond the codebook's magnitude, inf, NaN) yields inf / NaN scores, fails
+ * the margin test and is re-scanned exactly. Either way the winner's distance is recomputed with the reference's k-ordered
+ * chain and every point inside the error margin is re-scanned exactly (listed points several per codebook pass): identical
+ * results, distances and indices. */
 size_t c3dgs_weighted_distance_ws_bytes(int64_t N, int32_t C, int32_t K);
 int c3dgs_weighted_distance_ws(int64_t N, int32_t C, int32_t K, const float* coefs, const int64_t* gather,
                                const float* codebook, float* out_dist, int64_t* out_idx, void* ws, size_t ws_bytes,
                                void* stream);
 
-/* diagnostics for tests: scores[n * C + c] = ||c||^2 - 2 x_n.c as the split-bf16 search forms them (K = 48, N <= 256,
+/* diagnostics for tests: scores[n * C + c] = ||c||^2 - 2 x_n.c as the split-fp16 search forms them (fp32 accumulation of the three fp16 piece products,
+ * divided back by the call's scale) (K = 48, N <= 256,
  * C >= 32; ws as above), so the error the ambiguity margin must cover can be measured against float64. */
 int c3dgs_debug_wd_scores(int64_t N, int32_t C, int32_t K, const float* coefs, const float* codebook, float* scores, void* ws,
                           size_t ws_bytes, float* out_dist, int64_t* out_idx, void* stream);

@@ -841,6 +841,32 @@ void orc_test_cov3d(int n, const float* scales, float mod, const float* rots, fl
     for (int i = 0; i < n; i++) cov3d_from_scale_rot(scales + 3 * i, mod, rots + 4 * i, cov + 6 * i);
 }
 
+/* backward.cu:20-139 per Gaussian: dL_dsh [n,M,3] (written) and the SH part of dL_dmean [n,3] for upstream dL_dcolor [n,3]. */
+void orc_test_sh_backward(int n, int deg, int M, const float* pos, const float* campos, const float* sh,
+                          const uint8_t* clamped, const float* dL_dcolor, float* dL_dsh, float* dL_dmean)
+{
+    f3 cp = { campos[0], campos[1], campos[2] };
+    double* acc = (double*)malloc((size_t)M * 3 * sizeof(double));
+    for (int i = 0; i < n; i++) {
+        f3 p = { pos[3 * i], pos[3 * i + 1], pos[3 * i + 2] };
+        for (int k = 0; k < M * 3; k++) acc[k] = 0.0;
+        sh_backward(deg, M, p, cp, sh + (size_t)i * M * 3, clamped + 3 * i, dL_dcolor + 3 * i, acc, dL_dmean + 3 * i);
+        for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)i * M * 3 + k] = (float)acc[k];
+    }
+    free(acc);
+}
+
+/* backward.cu:278-341 per Gaussian: d_s [n,3] = the reference's dL_dscale (gradient w.r.t. mod * scale, :322-325) and
+ * dq [n,4] w.r.t. the UN-normalised quaternion (:340), for upstream dL_dcov3D [n,6]. */
+void orc_test_cov3d_backward(int n, const float* scales, float mod, const float* rots, const float* dL_dcov3D,
+                             float* d_s, float* dq)
+{
+    for (int i = 0; i < n; i++) {
+        const float s[3] = { mod * scales[3 * i], mod * scales[3 * i + 1], mod * scales[3 * i + 2] };   /* backward.cu:295 */
+        cov3d_backward(s, rots + 4 * i, dL_dcov3D + 6 * i, d_s + 3 * i, dq + 4 * i);
+    }
+}
+
 /* ---------------------------------------------------------------- N3: L1 + SSIM loss (utils/loss_utils.py:17-63)
  * loss = (1-lambda)*mean|x-y| + lambda*(1 - mean(ssim_map)), the QAT loss of finetune.py:48.
  * ssim: 11x11 Gaussian window (sigma 1.5, normalised in fp32 like `gaussian`/`create_window`, :23-31), zero padding 5,

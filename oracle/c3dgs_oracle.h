@@ -119,6 +119,10 @@ void orc_l1_ssim(int C, int H, int W, const float* img, const float* gt, double 
 void orc_test_color_from_sh(int n, int deg, int M, const float* pos, const float* campos, const float* sh,
                             int clamp_color, uint8_t* clamped, float* rgb);
 void orc_test_cov3d(int n, const float* scales, float mod, const float* rots, float* cov);
+void orc_test_sh_backward(int n, int deg, int M, const float* pos, const float* campos, const float* sh,
+                          const uint8_t* clamped, const float* dL_dcolor, float* dL_dsh, float* dL_dmean);
+void orc_test_cov3d_backward(int n, const float* scales, float mod, const float* rots, const float* dL_dcov3D,
+                             float* d_s, float* dq);
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,10 @@ def lib():
         _lib.orc_morton_codes.argtypes = [C.c_int, _f32p, _i64p, _i32p]
         _lib.orc_test_cov3d.restype = None
         _lib.orc_test_cov3d.argtypes = [C.c_int, _f32p, C.c_float, _f32p, _f32p]
+        _lib.orc_test_sh_backward.restype = None
+        _lib.orc_test_sh_backward.argtypes = [C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _u8p, _f32p, _f32p, _f32p]
+        _lib.orc_test_cov3d_backward.restype = None
+        _lib.orc_test_cov3d_backward.argtypes = [C.c_int, _f32p, C.c_float, _f32p, _f32p, _f32p, _f32p]
     return _lib
 
 
@@ -348,6 +352,26 @@ def cov3d(scales, mod, rotations):
     out = np.zeros((s.shape[0], 6), np.float32)
     lib().orc_test_cov3d(s.shape[0], _p(s, _f32p), float(mod), _p(q, _f32p), _p(out, _f32p))
     return out
+
+
+def sh_backward(deg, pos, campos, sh, dL_dcolor, clamped=None):
+    """backward.cu:20-139 -> (dL_dsh [n,M,3], SH part of dL_dmean [n,3])."""
+    pos, campos, sh, g = _f32(pos), _f32(campos), _f32(sh), _f32(dL_dcolor)
+    n, M = sh.shape[0], sh.shape[1]
+    cl = np.zeros((n, 3), np.uint8) if clamped is None else np.ascontiguousarray(clamped, dtype=np.uint8)
+    dsh, dmean = np.zeros((n, M, 3), np.float32), np.zeros((n, 3), np.float32)
+    lib().orc_test_sh_backward(n, int(deg), M, _p(pos, _f32p), _p(campos, _f32p), _p(sh, _f32p), _p(cl, _u8p), _p(g, _f32p),
+                               _p(dsh, _f32p), _p(dmean, _f32p))
+    return dsh, dmean
+
+
+def cov3d_backward(scales, mod, rotations, dL_dcov3D):
+    """backward.cu:278-341 -> (dL_dscale [n,3] (w.r.t. mod * scale, as the reference returns it), dL_drot [n,4] w.r.t. the
+    UN-normalised quaternion)."""
+    s, q, g = _f32(scales), _f32(rotations), _f32(dL_dcov3D)
+    ds, dq = np.zeros((s.shape[0], 3), np.float32), np.zeros((s.shape[0], 4), np.float32)
+    lib().orc_test_cov3d_backward(s.shape[0], _p(s, _f32p), float(mod), _p(q, _f32p), _p(g, _f32p), _p(ds, _f32p), _p(dq, _f32p))
+    return ds, dq
 
 
 # ----------------------------------------------------------------------------- N3: loss

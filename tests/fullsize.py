@@ -72,6 +72,114 @@ def flipped_pixels(u, st):
     return (u["n_contrib"] != st.n_contrib).reshape(st.H, st.W) | (np.abs(a - b) > 2e-5 + 1e-4 * np.abs(b)).any(0)
 
 
+# ---- float64 proof that a flipped pixel is a true fp32 borderline ---------------------------------------------------
+# Both implementations take, per (pixel, Gaussian) pair, the reference's three decisions (forward.cu:344-360, the same in
+# backward.cu:486-501):   power > 0 -> skip;   alpha = min(0.99, o * exp(power)) < 1/255 -> skip;   T * (1 - alpha) < 1e-4 -> stop.
+# They evaluate `power` from the SAME fp32 inputs (mean2D, conic, opacity and dx = mean.x - px, dy = mean.y - py are
+# bit-identical on both sides, asserted by compare()) but with different roundings: the oracle one rounding per operation in
+# the reference's order, the kernel three products + three FMAs on a conic pre-scaled by log2(e) feeding v_exp_f32.
+# With u = 2^-24, Q = 0.5 (a dx^2 + c dy^2), X = |b dx dy| (|power| <= Q + X):
+#   * either evaluation makes at most 3 roundings per product term and 1 per addition:
+#         |power_fp32 - power_exact| <= u (3 Q + 3 X + |power|)         -> E_P = u (4 (Q + X) + |power|)   (one u of slack per term)
+#   * exp (<= 1 ulp for expf and for v_exp_f32 of an exactly scaled argument... the scaling product is one more rounding,
+#     counted in E_P's slack), the product with the opacity (1 rounding) and min():   rel. error of alpha <= E_A = E_P + 3 u
+#   * T is a running product of (1 - alpha_k): every blended entry adds alpha_k E_A,k / (1 - alpha_k) + 2 u to its relative error.
+# A decision whose float64 value lies farther from its threshold than these bounds is taken identically by ANY correct fp32
+# evaluation. prove_flips() walks a flipped pixel's list in float64 from the bit-identical inputs, branches ONLY at decisions
+# inside their band and requires the kernel's (n_contrib, final_T, colour) and the oracle's to each equal one leaf of that
+# walk. A pixel whose kernel result matches no leaf is a flip OUTSIDE the band -- a real difference, not rounding.
+_U = 2.0 ** -24
+
+
+def _pixel_leaves(st, feat, x, y, max_leaves=256):
+    """All outcomes of pixel (x, y) reachable by flipping in-band decisions. -> list of (n_contrib, T, colour[3], decisions)
+    where decisions = [(kind, list position, margin / band)]; or None if there are more than max_leaves."""
+    gx = (st.W + 15) // 16
+    t = (y // 16) * gx + x // 16
+    lst = st.point_list[st.ranges[t, 0]:st.ranges[t, 1]].astype(np.int64)
+    A_THR, T_THR, A_MAX = float(np.float32(1.0) / np.float32(255.0)), float(np.float32(0.0001)), float(np.float32(0.99))
+    bg = st.inputs["bg"].astype(np.float64)
+    if lst.size == 0:
+        return [(0, 1.0, bg.copy(), [])]
+    m = st.means2D[lst]
+    dx = (m[:, 0] - np.float32(x)).astype(np.float64)              # the fp32 subtraction both sides perform (forward.cu:342)
+    dy = (m[:, 1] - np.float32(y)).astype(np.float64)
+    co = st.conic_opacity[lst].astype(np.float64)
+    qa, qc, xb = 0.5 * co[:, 0] * dx * dx, 0.5 * co[:, 2] * dy * dy, co[:, 1] * dx * dy
+    power = -(qa + qc) - xb
+    eP = _U * (4.0 * (np.abs(qa) + np.abs(qc) + np.abs(xb)) + np.abs(power))
+    with np.errstate(over="ignore", invalid="ignore"):
+        alpha = np.minimum(A_MAX, co[:, 3] * np.exp(np.minimum(power, 50.0)))
+    eA = eP + 3.0 * _U                                              # relative
+    col = feat[lst].astype(np.float64)
+    # entries every fp32 evaluation skips: power clearly positive, or alpha clearly below 1/255
+    surely_skipped = (power > eP) | ((alpha < A_THR) & (np.abs(alpha - A_THR) > alpha * eA))
+    cand = np.nonzero(~surely_skipped)[0]
+    leaves = []
+    # depth-first over in-band decisions; state = (index into cand, T, relative error bound of T, colour, last, decisions)
+    stack = [(0, 1.0, 0.0, np.zeros(3), 0, [])]
+    while stack:
+        ci, T, eT, C, last, dec = stack.pop()
+        stopped = False
+        while ci < cand.size:
+            j = int(cand[ci]); ci += 1
+            a, e = float(alpha[j]), float(eA[j])
+            if abs(power[j]) <= eP[j]:                               # power > 0 ?  (in band: both ways)
+                stack.append((ci, T, eT, C.copy(), last, dec + [("power>0", j, float(power[j] / eP[j]))]))   # the skip branch
+            elif power[j] > 0:
+                continue
+            if abs(a - A_THR) <= a * e:                              # alpha < 1/255 ?  (in band: both ways)
+                stack.append((ci, T, eT, C.copy(), last, dec + [("alpha<1/255", j, float((a - A_THR) / (a * e)))]))
+                dec = dec + [("alpha>=1/255", j, float((a - A_THR) / (a * e)))]
+            elif a < A_THR:
+                continue
+            test_T = T * (1.0 - a)
+            eS = eT + a * e / (1.0 - a) + 2.0 * _U                   # relative error bound of test_T
+            if abs(test_T - T_THR) <= T_THR * eS:                    # T (1 - alpha) < 1e-4 ?  (in band: both ways)
+                leaves.append((last, T, C + T * bg, dec + [("stop", j, float((test_T - T_THR) / (T_THR * eS)))]))
+                dec = dec + [("no stop", j, float((test_T - T_THR) / (T_THR * eS)))]
+            elif test_T < T_THR:
+                stopped = True
+                break
+            C = C + col[j] * (a * T)
+            T, eT, last = test_T, eS, j + 1
+        leaves.append((last, T, C + T * bg, dec))
+        if len(leaves) + len(stack) > max_leaves:
+            return None
+    return leaves
+
+
+def prove_flips(u, st, flipped):
+    """For every flipped pixel: does the kernel's result equal a leaf of the float64 walk, and the oracle's another?
+    -> dict(flips, outside_band, oracle_outside_band, decisions = [(kind, |margin| / band)] of the matched kernel leaves)."""
+    feat = st.inputs["colors_precomp"] if st.inputs["colors_precomp"] is not None else st.rgb
+    feat = feat.reshape(st.P, 3)
+    out = dict(flips=int(flipped.sum()), outside_band=0, oracle_outside_band=0, decisions=[])
+
+    def matches(leaf, nc, T, colour):
+        n_l, T_l, C_l, _ = leaf
+        return (n_l == int(nc) and abs(T_l - float(T)) <= 2e-4 * max(T_l, 1e-4)
+                and bool(np.all(np.abs(C_l - colour.astype(np.float64)) <= 2e-5 + 2e-4 * np.abs(C_l))))
+
+    ys, xs = np.nonzero(flipped)
+    for y, x in zip(ys.tolist(), xs.tolist()):
+        pix = y * st.W + x
+        leaves = _pixel_leaves(st, feat, x, y)
+        if leaves is None:
+            out["outside_band"] += 1
+            continue
+        hip_leaf = [l for l in leaves if matches(l, u["n_contrib"][pix], u["final_T"][pix], u["out_color"][:, y, x])]
+        orc_leaf = [l for l in leaves if matches(l, st.n_contrib[pix], st.final_T[pix], st.out_color[:, y, x])]
+        if not hip_leaf:
+            out["outside_band"] += 1
+        else:
+            best = min(hip_leaf, key=lambda l: len(l[3]))
+            out["decisions"] += [(k, abs(r)) for k, _, r in best[3]]
+        if not orc_leaf:
+            out["oracle_outside_band"] += 1
+    return out
+
+
 def grad_errors(st, flipped, got, ref):
     """rel-inf error of every gradient, over everything and over the Gaussians (or codebook rows) that share NO 16x16 tile
     with a flipped pixel (the others legitimately differ by that pixel's term). -> (errs, errs_clean, affected count)"""
@@ -104,10 +212,15 @@ def check_grads(st, u, got, ref, tol, what=""):
     """The gradient bar of the parity tests, aware of flipped pixels: every gradient within `tol` (rel-inf) -- or, when the
     forward has flipped pixels, within `tol` over everything that shares no tile with one and within 5 x tol overall
     (a flipped pixel adds or drops one whole contribution for the Gaussians of its tile). At most max(2, 2e-5 x pixels)
-    pixels may flip. -> number of flipped pixels"""
+    pixels may flip, and EVERY flipped pixel must be proven a true fp32 borderline by prove_flips (the kernel's result and
+    the oracle's each equal a leaf of a float64 walk that branches only at decisions inside their fp32 error band).
+    -> number of flipped pixels"""
     flipped = flipped_pixels(u, st) if st.num_rendered > 0 else np.zeros((st.H, st.W), bool)
     n_flip = int(flipped.sum())
     assert n_flip <= max(2, int(2e-5 * st.W * st.H)), f"{what}: {n_flip} flipped pixels"
+    if n_flip:          # every flip must be a PROVEN fp32 borderline (float64 walk, see prove_flips), not merely rare
+        proof = prove_flips(u, st, flipped)
+        assert proof["outside_band"] == 0 and proof["oracle_outside_band"] == 0, f"{what}: flip outside the fp32 band: {proof}"
     clean = grad_errors(st, flipped, got, ref)[1] if n_flip else None
     for k, v in got.items():
         r = ref[k]
@@ -157,6 +270,10 @@ def compare(inp, cam, indexed, st, ref=None, dL=None, fw=None):
     out["deepest_blend"] = int(st.n_contrib.max()) if st.n_contrib.size else 0
     flipped = flipped_pixels(u, st)
     out["flipped_pixels"] = int(flipped.sum())
+    proof = prove_flips(u, st, flipped)
+    out["flips_outside_band"] = proof["outside_band"] + proof["oracle_outside_band"]
+    out["flip_decisions"] = sorted({k for k, _ in proof["decisions"]})
+    out["flip_margin_over_band_max"] = max([r for _, r in proof["decisions"]], default=0.0)
     if ref is not None:
         got = gpu_util.hip_backward(fw, dL)
         errs, errs_clean, n_aff = grad_errors(st, flipped, got, ref)

@@ -9,6 +9,16 @@ What it pins; the fixtures hold data only (inputs + exp
                  argmin) and its RNG draws (rand_like of uniform_init, randint batches) captured as data
   sh.npz         utils/sh_utils.py:eval_sh                       -> K2's SH->RGB (before +0.5 / clamp)
   cov3d.npz      utils/general_utils.py:build_covariance_from_scaling_rotation -> K2's cov3D
+  sh_bwd.npz     torch.autograd THROUGH eval_sh on dirs = normalize(pos - campos), as the reference's own python colour path
+                 does (scene/gaussian_model.py:828-832): d/dsh and d/dpos -> pins backward.cu:20-139 (SH backward incl. the
+                 direction-normalisation Jacobian dnormvdv); positions lie in front of a posed camera so that the same
+                 fixture can be rasterized on the GPU
+  cov3d_bwd.npz  torch.autograd through build_covariance_from_scaling_rotation: Jacobians d cov6 / d scale and
+                 d cov6 / d rotation (the reference's build_rotation normalises q, so for unit q this is the TANGENTIAL part
+                 of the kernel's un-normalised-quaternion gradient) + one random upstream -> pins backward.cu:278-341
+  vq_d48.npz     vq_features at D = 48 (N=20000, K=512, 8 steps of 4096), seed-only: features / importance come from a seeded
+  vq_config0.npz generator, the draws from torch.manual_seed -- and BASELINE.json configs[0] exactly (N=10000, D=12, K=256,
+                 100 steps of 2^14, seed 0). Stored: seeds, the uniform_init draw, final codebook, final indices, per-step error
   loss.npz       utils/loss_utils.py: (1-l)*l1_loss + l*(1-ssim) and its autograd gradient (finetune.py:48)
   morton.npz     mortonEncode/splitBy3 (scene/gaussian_model.py:1417-1432) on _sort_morton's quantisation (:999-1003)
   splats.npz     utils/splats.py: extract_rot_scale(to_full_cov(cov6)) and build_covariance of its result (pure torch,
@@ -122,6 +132,109 @@ def gen_cov3d():
         out[f"cov_mod{mod}"] = build_covariance_from_scaling_rotation(s, mod, q).numpy()
     np.savez_compressed(os.path.join(OUT, "cov3d.npz"), scales=s.numpy(), rotations=q.numpy(), **out)
     print("cov3d.npz")
+
+
+def gen_sh_bwd():
+    """autograd through utils/sh_utils.py:eval_sh on normalised view directions (the reference's python colour path,
+    scene/gaussian_model.py:828-832: dir_pp = xyz - camera_center; dir_pp / dir_pp.norm(); eval_sh)."""
+    import math
+    from utils.sh_utils import eval_sh
+    src = open(os.path.join(REF, "submodules/diff-gaussian-rasterization-no-camera/"
+                                 "diff_gaussian_rasterization_no_camera/__init__.py")).read().split("\n")
+    ns = dict(torch=torch, math=math)
+    exec("\n".join(src[18:52]).replace(".cuda()", ""), ns)            # getProjectionMatrix / quat_to_mat (see gen_camera)
+    g = torch.Generator().manual_seed(15)
+    P, W, H, focal = 257, 160, 112, 120.0
+    q = torch.tensor([0.05, -0.03, 0.02, 0.99])
+    ev = torch.cat([q, torch.tensor([0.1, -0.05, 0.2])]).float()
+    intr = torch.tensor([[2 * math.atan(W / (2 * focal)), 0, float(W)], [0, 2 * math.atan(H / (2 * focal)), float(H)], [0, 0, 1]],
+                        dtype=torch.float32)
+    view = ns["quat_to_mat"](ev)                                       # W2C transposed (row-vector convention)
+    campos = view.inverse()[3, :3]                                     # __init__.py:176
+    # points in camera space in front of the camera, mapped to world space with the inverse pose: p_c = p_w @ view[:3,:3] + view[3,:3]
+    z = torch.rand(P, generator=g) * 4 + 2
+    pc = torch.stack([(torch.rand(P, generator=g) * 2 - 1) * z * W / (2 * focal) * 0.9,
+                      (torch.rand(P, generator=g) * 2 - 1) * z * H / (2 * focal) * 0.9, z], 1).double()
+    pos = ((pc - view[3, :3].double()) @ view[:3, :3].double().inverse()).float().contiguous()
+    sh = torch.randn(P, 16, 3, generator=g).float() * 0.3
+    sh[:, 0] = torch.randn(P, 3, generator=g) * 0.5
+    up = torch.randn(P, 3, generator=g).float()
+    out = dict(pos=pos.numpy(), campos=campos.numpy(), extrinsic_vector=ev.numpy(), intrinsic=intr.numpy(), sh=sh.numpy(),
+               upstream=up.numpy(), W=np.array(W), H=np.array(H))
+    for deg in range(4):
+        shp = sh.clone().requires_grad_()
+        posp = pos.clone().requires_grad_()
+        d = posp - campos
+        d = d / d.norm(dim=1, keepdim=True)
+        rgb = eval_sh(deg, shp.transpose(1, 2), d)
+        (rgb * up).sum().backward()
+        out[f"dsh_deg{deg}"] = shp.grad.numpy()
+        out[f"dpos_deg{deg}"] = posp.grad.numpy() if posp.grad is not None else np.zeros((P, 3), np.float32)   # deg 0: no direction
+        shp2 = sh.clone().requires_grad_()
+        d2 = pos - campos
+        eval_sh(deg, shp2.transpose(1, 2), d2 / d2.norm(dim=1, keepdim=True))[:, 0].sum().backward()
+        out[f"basis_deg{deg}"] = shp2.grad[:, :, 0].numpy()           # d rgb[p, c] / d sh[p, k, c] = basis_k(dir_p), any c
+    np.savez_compressed(os.path.join(OUT, "sh_bwd.npz"), **out)
+    print("sh_bwd.npz")
+
+
+def gen_cov3d_bwd():
+    """autograd through utils/general_utils.py:build_covariance_from_scaling_rotation (strip_symmetric(L L^T), L = R(q/|q|) S)."""
+    from utils.general_utils import build_covariance_from_scaling_rotation
+    g = torch.Generator().manual_seed(16)
+    P = 257
+    s = torch.exp(torch.randn(P, 3, generator=g) * 0.5 - 3.2).float()
+    q = torch.randn(P, 4, generator=g)
+    q = (q / q.norm(dim=1, keepdim=True)).float()
+    up = torch.randn(P, 6, generator=g).float()
+    out = dict(scales=s.numpy(), rotations=q.numpy(), upstream=up.numpy())
+    for mod in (1.0, 1.7):
+        js, jq = np.zeros((P, 6, 3), np.float32), np.zeros((P, 6, 4), np.float32)
+        for k in range(6):
+            sp, qp = s.clone().requires_grad_(), q.clone().requires_grad_()
+            build_covariance_from_scaling_rotation(sp, mod, qp)[:, k].sum().backward()
+            js[:, k], jq[:, k] = sp.grad.numpy(), qp.grad.numpy()
+        sp, qp = s.clone().requires_grad_(), q.clone().requires_grad_()
+        (build_covariance_from_scaling_rotation(sp, mod, qp) * up).sum().backward()
+        out.update({f"jac_scale_mod{mod}": js, f"jac_rot_mod{mod}": jq, f"dscale_mod{mod}": sp.grad.numpy(),
+                    f"drot_mod{mod}": qp.grad.numpy()})
+    np.savez_compressed(os.path.join(OUT, "cov3d_bwd.npz"), **out)
+    print("cov3d_bwd.npz")
+
+
+def seeded_vq_inputs(N, D, data_seed):
+    """The synthetic features / importance of SURVEY 8(d) config 1, from a seeded CPU generator (regenerated by the tests)."""
+    g = torch.Generator().manual_seed(data_seed)
+    f = (torch.randn(N, D, generator=g) * 0.1).float()
+    imp = torch.rand(N, generator=g).pow(4).float()
+    return f, imp
+
+
+def gen_vq_seeded(vq, name, N, D, K, steps, chunk, data_seed, seed):
+    """vq_features driven by torch.manual_seed(seed) only: VectorQuantize.__init__'s kaiming_uniform_ (vq.py:19-21), the
+    rand_like of uniform_init (:26) and every randint batch (:69) come from the CPU default generator in that order."""
+    f, imp = seeded_vq_inputs(N, D, data_seed)
+    draws = {"rand": None}
+    orig_rand_like = torch.rand_like
+
+    def rand_like(t, *a, **k):
+        r = orig_rand_like(t, *a, **k)
+        draws["rand"] = r.clone()
+        return r
+    errors = []
+    import builtins
+    torch.manual_seed(seed)
+    torch.rand_like = rand_like
+    try:
+        cb, idx = vq.vq_features(f, imp, K, chunk, steps, silent=True)
+    finally:
+        torch.rand_like = orig_rand_like
+    np.savez_compressed(os.path.join(OUT, name), N=np.array(N), D=np.array(D), K=np.array(K), steps=np.array(steps),
+                        chunk=np.array(chunk), data_seed=np.array(data_seed), seed=np.array(seed),
+                        init_rand=draws["rand"].numpy(), codebook=cb.numpy(),
+                        indices=idx.numpy().astype(np.int16 if K <= 32767 else np.int32),
+                        features_checksum=np.array(float(f.double().sum())), importance_checksum=np.array(float(imp.double().sum())))
+    print(name, "codebook", tuple(cb.shape))
 
 
 def gen_camgrad():
@@ -261,11 +374,25 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["camera"]:
         gen_camera()
         sys.exit(0)
+    if sys.argv[1:] == ["bwd"]:
+        sys.path.insert(0, REF)
+        gen_sh_bwd()
+        gen_cov3d_bwd()
+        sys.exit(0)
+    if sys.argv[1:] == ["vq_seeded"]:
+        vq = shim_and_import_vq()
+        gen_vq_seeded(vq, "vq_d48.npz", N=20000, D=48, K=512, steps=8, chunk=4096, data_seed=48, seed=3)
+        gen_vq_seeded(vq, "vq_config0.npz", N=10000, D=12, K=256, steps=100, chunk=2 ** 14, data_seed=0, seed=0)
+        sys.exit(0)
     vq = shim_and_import_vq()
     gen_vq(vq, "vq_color.npz", N=3000, D=12, K=64, steps=12, chunk=1024, scale_normalize=False, seed=0)
     gen_vq(vq, "vq_cov.npz", N=2500, D=6, K=32, steps=10, chunk=512, scale_normalize=True, seed=1)
+    gen_vq_seeded(vq, "vq_d48.npz", N=20000, D=48, K=512, steps=8, chunk=4096, data_seed=48, seed=3)
+    gen_vq_seeded(vq, "vq_config0.npz", N=10000, D=12, K=256, steps=100, chunk=2 ** 14, data_seed=0, seed=0)
     gen_sh()
     gen_cov3d()
+    gen_sh_bwd()
+    gen_cov3d_bwd()
     gen_camgrad()
     gen_camera()
     gen_loss()

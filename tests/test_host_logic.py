@@ -309,3 +309,19 @@ def test_pipeline_parameter_defaults_and_lr_schedule():
     g = model.get_expon_lr_func(1e-2, 1e-4, lr_delay_steps=100, lr_delay_mult=0.1, max_steps=1000)
     assert g(0) == pytest.approx(1e-2 * 0.1)
     assert g(50) == pytest.approx((0.1 + 0.9 * math.sin(0.25 * math.pi)) * math.exp(math.log(1e-2) * 0.95 + math.log(1e-4) * 0.05))
+
+
+def test_vq_features_host_logic_replays_the_reference_from_a_seed_alone():
+    """c3dgs_amd.vq.vq_features (host logic; compute injected from the oracle, the product has no CPU path) against
+    tests/golden/vq_config0.npz = the reference's own vq_features run from torch.manual_seed(0) on BASELINE.json configs[0]
+    exactly: same kaiming_uniform_ consumption in VectorQuantize.__init__, same randint batches, same result."""
+    import numpy as np
+    from c3dgs_amd import vq
+    from tests import vq_fixture
+    from tests.oracle_ops import OracleOps
+    fx = vq_fixture.load("vq_config0.npz")
+    vq_fixture.seed_like_reference(fx)
+    cb, idx = vq.vq_features(fx["features"], fx["importance"], fx["K"], fx["chunk"], fx["steps"], silent=True,
+                             init_rand=fx["init_rand"], ops=OracleOps)
+    np.testing.assert_allclose(cb.numpy(), fx["codebook"], rtol=1e-4, atol=2e-7)
+    assert (idx.numpy() == fx["indices"]).mean() >= 0.999

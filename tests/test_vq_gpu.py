@@ -83,10 +83,37 @@ def test_vq_update_matches_oracle(hip, orc, D, K, scale_normalize):
         np.testing.assert_allclose(md.cpu().numpy(), md_ref, rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("D,K,tails", [(48, 4096, (17, 21, 25, 63, 1)), (6, 4096, (10, 19, 33, 5)), (12, 2048, (7, 29, 50))])
+def test_vq_accumulate_ragged_tail_chunks(hip, D, K, tails):
+    """c3dgs_vq_accumulate on batches whose LAST 64-point chunk is ragged: the dense (no shared codeword) path broadcasts a
+    point's row / weight / codeword by lane shuffles, which must run with every lane active (round-2 advisory: tails with
+    (cnt * (D+1)) % 64 in 1..cnt-1 lost contributions). K * (D+1) > 16384 selects that kernel; all indices distinct so the
+    dense path is the one taken. Checked against float64 sums of compression/vq.py:31-34."""
+    import ctypes as C
+    from c3dgs_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(77 + D)
+    for tail in tails:
+        for B in (tail, 64 * 5 + tail):
+            x = torch.randn(B, D, generator=g).float()
+            w = (torch.rand(B, generator=g) + 0.5).float()
+            idx = torch.randperm(K, generator=g)[:B].contiguous()          # distinct codewords -> no merging
+            S = torch.zeros(K, D + 1, device="cuda")
+            xd, wd, id_ = x.cuda(), w.cuda(), idx.cuda()
+            rc = L.c3dgs_vq_accumulate(B, K, D, xd.data_ptr(), wd.data_ptr(), None, id_.data_ptr(), None, S.data_ptr(), None,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0
+            ref = np.zeros((K, D + 1))
+            np.add.at(ref[:, :D], idx.numpy(), x.numpy().astype(np.float64) * w.numpy()[:, None].astype(np.float64))
+            np.add.at(ref[:, D], idx.numpy(), w.numpy().astype(np.float64))
+            np.testing.assert_allclose(S.cpu().numpy(), ref, rtol=1e-6, atol=1e-7, err_msg=f"D={D} B={B}")
+
+
 def test_vq_features_matches_oracle(hip, orc):
-    """Config 1 of BASELINE.json (10k Gaussians, SH degree 1 -> D=12, K=256), RNG draws passed as data."""
+    """Config 1 of BASELINE.json at its FULL size (10k Gaussians, SH degree 1 -> D=12, K=256, 100 steps of 2^14), RNG draws
+    passed as data to both sides."""
     g = torch.Generator().manual_seed(0)
-    N, D, K, steps, chunk = 10_000, 12, 256, 20, 2 ** 12
+    N, D, K, steps, chunk = 10_000, 12, 256, 100, 2 ** 14
     f = (torch.randn(N, D, generator=g) * 0.1).float()
     imp = torch.rand(N, generator=g).pow(4).float()
     init = torch.rand(K, D, generator=g)
@@ -98,6 +125,27 @@ def test_vq_features_matches_oracle(hip, orc):
     agree = (idx.cpu().numpy() == idx_ref).mean()
     assert agree >= 0.999, agree
     np.testing.assert_allclose(np.array(errs), err_ref, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["vq_config0.npz", "vq_d48.npz"])
+def test_vq_features_hip_vs_reference_fixture_from_seed_alone(hip, name):
+    """The HIP path DIRECTLY against the reference's own vq_features (compression/vq.py:49-87, run by
+    tests/golden/make_golden.py from torch.manual_seed alone): vq_config0.npz is BASELINE.json configs[0] exactly (N = 10k,
+    D = 12, K = 256, 100 x 2^14), vq_d48.npz the colour codebook's width (N = 20k, D = 48, K = 512, 8 x 4096). The batches
+    are NOT data here: the package continues the CPU generator's MT19937 stream itself (_BatchDraws / csrc/draws.hip)."""
+    from tests import vq_fixture
+    fx = vq_fixture.load(name)
+    vq_fixture.seed_like_reference(fx)
+    cb, idx = hip.vq_features(fx["features"].cuda(), fx["importance"].cuda(), fx["K"], fx["chunk"], fx["steps"], silent=True,
+                              init_rand=fx["init_rand"])
+    np.testing.assert_allclose(cb.cpu().numpy(), fx["codebook"], rtol=1e-4, atol=2e-7)
+    assert (idx.cpu().numpy() == fx["indices"]).mean() >= 0.999
+    # the generator is left where the reference's loop leaves it: the next draw equals the one after `steps` batches
+    nxt = torch.randint(0, 1 << 30, (4,))
+    vq_fixture.seed_like_reference(fx, model_built_inside=False)
+    for _ in range(fx["steps"]):
+        torch.randint(low=0, high=fx["N"], size=[fx["chunk"]])
+    assert torch.equal(nxt, torch.randint(0, 1 << 30, (4,)))
 
 
 def test_weighted_distance_full_size_properties(hip):
