@@ -59,7 +59,9 @@ def _compile(name, extra, verbose):
 # Test-only variants of the library: same sources, extra flags for some files; objects of untouched files are shared with
 # the product build. "spin1": every look-back of the radix sorts gives up after ONE poll, which forces the time-out path
 # that tests/test_sort_gpu.py::test_sort_timeout_is_not_silent exercises (loaded through C3DGS_LIB_PATH in a child process).
-VARIANTS = {"spin1": {"radix_sort.hip": ["-DC3DGS_OS_SPIN_LIMIT=1u"]}}
+# "lanes": the blend kernels count how many pixel lanes use each (wave, Gaussian) pair (tools/lane_efficiency.py).
+VARIANTS = {"spin1": {"radix_sort.hip": ["-DC3DGS_OS_SPIN_LIMIT=1u"]},
+            "lanes": {"render.hip": ["-DC3DGS_COUNT_LANES"]}}
 
 
 def build_variant(name, verbose=False):

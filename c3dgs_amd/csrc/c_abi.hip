@@ -328,6 +328,15 @@ int c3dgs_profile_read(c3dgs_stage_time* out, int capacity)
 }
 int c3dgs_abi_version(void) { return C3DGS_ABI_VERSION; }
 
+int c3dgs_debug_lane_counters(uint64_t* out, void* stream)
+{
+    if (!out) return fail(C3DGS_E_INVALID, "debug_lane_counters: NULL buffer");
+    unsigned long long v[16];
+    if (read_lane_counters(v, (hipStream_t)stream)) return fail(C3DGS_E_HIP, "debug_lane_counters: copy failed");
+    for (int i = 0; i < 16; i++) out[i] = (uint64_t)v[i];
+    return C3DGS_OK;
+}
+
 size_t c3dgs_debug_sort_temp_bytes(int32_t key_bytes, int64_t n, int32_t end_bit)
 {
     if (n <= 0 || n > 0x3fffffff) return 256;

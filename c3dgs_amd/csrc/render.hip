@@ -26,6 +26,49 @@ namespace c3dgs {
 
 constexpr int BATCH = 256;
 
+// Lane-efficiency counters of the blend kernels (test-only build variant "lanes": -DC3DGS_COUNT_LANES, c3dgs_amd/build.py).
+// [fwd = 0 | bwd = 8] + { 0: (wave, Gaussian) pairs the blend loop ran (real list entries), 1: slots incl. the sentinel padding,
+// 2: lanes whose pixel used the pair (forward: blended it; backward: hit), 3: pairs with at least one such lane,
+// 4: sum over (wave, list) of max(pairs touching pixel rows 0-3, pairs touching rows 4-7) = iterations of a half-wave
+//    (8x4-pixel) scheduling unit, 5: the same for four 4x4-pixel blocks, 6: lists walked, 7: lanes hit (forward, incl. finished pixels) }
+// The product build never touches them; c3dgs_debug_lane_counters() reads and clears them.
+__device__ unsigned long long g_lane_counters[16];
+
+#ifdef C3DGS_COUNT_LANES
+struct LaneCount {
+    unsigned long long pairs = 0, slots = 0, lanes = 0, live = 0, half = 0, blk = 0, lists = 0, aux = 0;
+    int nA = 0, nB = 0, nb[4] = { 0, 0, 0, 0 };
+    __device__ void pair(bool real, unsigned long long used, unsigned long long aux_mask)
+    {
+        slots++;
+        if (!real) return;
+        pairs++;
+        lanes += __popcll(used);
+        aux += __popcll(aux_mask);
+        live += used != 0;
+        nA += (used & 0x00000000ffffffffull) != 0;
+        nB += (used & 0xffffffff00000000ull) != 0;
+        nb[0] += (used & 0x000000000f0f0f0full) != 0;
+        nb[1] += (used & 0x00000000f0f0f0f0ull) != 0;
+        nb[2] += (used & 0x0f0f0f0f00000000ull) != 0;
+        nb[3] += (used & 0xf0f0f0f000000000ull) != 0;
+    }
+    __device__ void end_list()
+    {
+        lists++;
+        half += max(nA, nB);
+        blk += max(max(nb[0], nb[1]), max(nb[2], nb[3]));
+        nA = nB = nb[0] = nb[1] = nb[2] = nb[3] = 0;
+    }
+    __device__ void flush(int base, int lane)
+    {
+        if (lane != 0) return;
+        const unsigned long long v[8] = { pairs, slots, lanes, live, half, blk, lists, aux };
+        for (int q = 0; q < 8; q++) atomicAdd(&g_lane_counters[base + q], v[q]);
+    }
+};
+#endif
+
 // The staged LDS records carry the conic PRE-SCALED for the blend loops: {-0.5 a, -b, -0.5 c} x log2(e), so that the
 // exponent of  G = exp(-0.5 (a dx^2 + c dy^2) - b dx dy)  is three multiplies and three multiply-adds feeding v_exp_f32
 // (= 2^x) directly: two vector instructions per (pixel, Gaussian) pair fewer than the reference's form + exp (which is
@@ -181,6 +224,9 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_contributor = 0;
     constexpr uint32_t NO_ENTRY = 0xffffffffu;
+#ifdef C3DGS_COUNT_LANES
+    LaneCount lc;
+#endif
     const char* rec_base = reinterpret_cast<const char*>(&s_ab[0][0][0]);
     const char* blue_base = reinterpret_cast<const char*>(&s_c[0][0]);
 
@@ -252,8 +298,14 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
                 Tr = blend ? test_T : Tr;
                 last_off = blend ? e[g] : last_off;
                 done = done || stop;
+#ifdef C3DGS_COUNT_LANES
+                lc.pair(k + g < nw, __ballot(blend), __ballot(hit));
+#endif
             }
         }
+#ifdef C3DGS_COUNT_LANES
+        lc.end_list();
+#endif
         // offset -> 1-based position in the tile's list (once per batch, not per Gaussian)
         if (last_off != NO_ENTRY) last_contributor = (uint32_t)(r * BATCH) + ((last_off - (uint32_t)buf * BUF_BYTES) >> 5) + 1u;
     }
@@ -267,6 +319,9 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
         out_color[HW + pix] = fmaf(Tr, bg[1], C1) + poison;
         out_color[2 * HW + pix] = fmaf(Tr, bg[2], C2) + poison;
     }
+#ifdef C3DGS_COUNT_LANES
+    lc.flush(0, lane);
+#endif
     // tile_used = max over the tile's pixels of n_contrib: the backward never looks past it
     atomicMax(&s_used, last_contributor);
     __syncthreads();
@@ -447,6 +502,9 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     // where this lane's reduced values belong: Gaussian slot beta of the group, term my_m of the nine (see the network above)
     const int beta = ((lane >> 2) & 1) * 4 + (lane & 1) * 2 + ((lane >> 1) & 1);
     const int my_m = ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
+#ifdef C3DGS_COUNT_LANES
+    LaneCount lc;
+#endif
 
     for (int r = 0; r < rounds; r++) {
         __syncthreads();                                         // previous flush has read s_part / s_slot
@@ -516,6 +574,9 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                 float dx, dy, G, alpha;
                 bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
                 hit = hit && ((int)e[g] > thr);                  // backward.cu:486-488
+#ifdef C3DGS_COUNT_LANES
+                lc.pair(k + g < nw, __ballot(hit), 0ull);
+#endif
                 // branch-free: a pixel that does not blend this Gaussian runs the same instructions with
                 // alpha = G = 0, which leaves T and Sd untouched and makes all six terms exactly 0
                 const float a_eff = hit ? alpha : 0.f, G_eff = hit ? G : 0.f;
@@ -553,6 +614,9 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                 if (lane < 8) __hip_atomic_fetch_add(&s_part[wave >> 1][myj][8], ninth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+#ifdef C3DGS_COUNT_LANES
+        lc.end_list();
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the list is rebuilt for the second half
         __builtin_amdgcn_wave_barrier();
         }
@@ -570,6 +634,17 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             touched[slot] = 1;
         }
     }
+#ifdef C3DGS_COUNT_LANES
+    lc.flush(8, lane);
+#endif
+}
+
+int read_lane_counters(unsigned long long* out16, hipStream_t s)
+{
+    static const unsigned long long zeros[16] = { 0 };
+    if (hipStreamSynchronize(s) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lane_counters), sizeof(zeros)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lane_counters), zeros, sizeof(zeros)) != hipSuccess;
 }
 
 // tile schedule + the backward's fills in one launch; zero_a / zero_b: 16-byte aligned spans of n16 x 16 bytes (or null / 0)

@@ -358,6 +358,13 @@ size_t c3dgs_debug_sort_temp_bytes(int32_t key_bytes, int64_t n, int32_t end_bit
 int c3dgs_debug_sort_pairs(int32_t key_bytes, int64_t n, int32_t end_bit, const void* keys_in, void* keys_out,
                            const uint32_t* values_in, uint32_t* values_out, void* temp, size_t temp_bytes, void* stream);
 
+/* tests / profiling only: lane-efficiency counters of the two blend kernels, accumulated since the last call and cleared by it.
+ * out[0..7] forward, out[8..15] backward: { (wave, Gaussian) pairs run, slots incl. list padding, pixel lanes that used the pair,
+ * pairs with >= 1 such lane, iterations an 8x4-pixel half-wave unit would run, iterations a 4x4-pixel unit would run,
+ * candidate lists walked, forward: lanes hit incl. finished pixels }. All zero unless the library is the "lanes" build
+ * variant (render.hip compiled with -DC3DGS_COUNT_LANES; c3dgs_amd/build.py VARIANTS). Synchronises the stream. */
+int c3dgs_debug_lane_counters(uint64_t* out /*[16], host*/, void* stream);
+
 int c3dgs_get_geom_layout(int32_t P, c3dgs_geom_layout* out);
 int c3dgs_get_binning_layout(int32_t R, int32_t W, int32_t H, c3dgs_binning_layout* out);
 int c3dgs_get_image_layout(int32_t W, int32_t H, c3dgs_image_layout* out);
