@@ -2,7 +2,8 @@
 
 Drop-in for the reference's two native extensions and the Python directly around them:
 
-    c3dgs_amd.rasterizer  <->  diff_gaussian_rasterization_no_camera (and its two sibling packages)
+    c3dgs_amd.rasterizer  <->  diff_gaussian_rasterization_no_camera (quaternion `extrinsic_vector` API)
+    c3dgs_amd.rasterizer_matrix <-> diff_gaussian_rasterization / diff_gaussian_rasterization_camera (4x4 `extrinsic` API)
     c3dgs_amd.vq          <->  weighted_distance._C.weightedDistance + compression/vq.py
     c3dgs_amd.loss        <->  utils/loss_utils.py (l1_loss, ssim) + the fused QAT loss of finetune.py:48
     c3dgs_amd.sensitivity <->  compress.py:calc_importance_experimental (camera-sharded)
@@ -16,7 +17,7 @@ The numeric work runs in c3dgs_amd/libc3dgs_hip.so (include/c3dgs_hip.h); build 
 import sys
 import types
 
-from . import encode, loss, model, optim, rasterizer, sensitivity, vq  # noqa: F401
+from . import encode, loss, model, optim, rasterizer, rasterizer_matrix, sensitivity, vq  # noqa: F401
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, GaussianRasterizerIndexed,  # noqa: F401
                          getProjectionMatrix, mat_to_quat, quat_to_mat, rasterize_gaussians,
                          rasterize_gaussians_indexed, rasterize_gaussians_indexed_camera)
@@ -32,9 +33,9 @@ __version__ = "0.1.0"
 def install_as_reference_modules():
     """Register this package under the module names the reference imports
     (scene/gaussian_model.py:43-44, compression/vq.py:12), so the reference's Python runs unmodified."""
-    for name in ("diff_gaussian_rasterization_no_camera", "diff_gaussian_rasterization",
-                 "diff_gaussian_rasterization_camera"):
-        sys.modules[name] = rasterizer
+    sys.modules["diff_gaussian_rasterization_no_camera"] = rasterizer
+    for name in ("diff_gaussian_rasterization", "diff_gaussian_rasterization_camera"):   # the matrix-`extrinsic` siblings
+        sys.modules[name] = rasterizer_matrix
     wd = types.ModuleType("weighted_distance")
     wdc = types.ModuleType("weighted_distance._C")
     wdc.weightedDistance = lambda coefs, codebook: weightedDistance(coefs, codebook)

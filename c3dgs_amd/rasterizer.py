@@ -171,6 +171,19 @@ def camera_matrices(intrinsic, extrinsic_vector, device, _guard=None):
     dev = torch.device(device)
     sc, vals, cached = _intrinsic_scalars(intrinsic)
     tanfovx, tanfovy, image_height, image_width, inv_x, inv_y = sc
+    if extrinsic_vector.dim() == 2:
+        # the sibling packages' pose: the 4x4 world->camera matrix itself (transposed, as quat_to_mat returns it), set up with
+        # the reference's own three tensor operations (diff_gaussian_rasterization/__init__.py:129-135): stream-ordered torch
+        # ops on the pose's device, nothing cached on the host
+        if tuple(extrinsic_vector.shape) != (4, 4):
+            raise RuntimeError("extrinsic must be a 4x4 matrix")
+        if _guard is not None and dev.type == "cuda":
+            _guard.append(_IntrinsicGuard(intrinsic, vals, cached))
+        view = extrinsic_vector.detach().to(device=dev, dtype=torch.float32).contiguous()
+        pa, pb = np.float32(1.0 * 100.0 / (100.0 - 0.01)), np.float32(-(100.0 * 0.01) / (100.0 - 0.01))
+        P = torch.tensor([[inv_x, 0.0, 0.0, 0.0], [0.0, inv_y, 0.0, 0.0], [0.0, 0.0, float(pa), float(pb)], [0.0, 0.0, 1.0, 0.0]],
+                         dtype=torch.float32).transpose(0, 1).contiguous().to(dev)      # == getProjectionMatrix(intrinsic)
+        return view, (view @ P).contiguous(), view.inverse()[3, :3].contiguous(), tanfovx, tanfovy, image_height, image_width
     if dev.type != "cuda":
         view, proj, campos = _camera_on_host(sc, extrinsic_vector)
         return view, proj, campos, tanfovx, tanfovy, image_height, image_width

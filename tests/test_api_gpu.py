@@ -283,3 +283,64 @@ def test_abs_accumulate_entry_point(hip):
         torch.cuda.synchronize()
         assert torch.equal(acc, want), (n, off)
     assert L.c3dgs_abs_accumulate(5, None, None, None) == 1
+
+
+def test_matrix_extrinsic_api_of_the_sibling_packages(hip, orc):
+    """diff_gaussian_rasterization / diff_gaussian_rasterization_camera (reference __init__.py:41-96, 503-659): settings
+    without a pose, `extrinsic=` 4x4 on forward / markVisible. Same kernels: the render and every gradient must equal the
+    quaternion API's for the same pose (the camera set-up differs only by torch's matmul / inverse round-off), and
+    install_as_reference_modules() must hand out THIS module under both sibling names."""
+    import sys
+    import c3dgs_amd
+    from c3dgs_amd import rasterizer_matrix as rm
+    W, H, focal = 200, 136, 125.0
+    intr, ev = synth.camera(W, H, focal, extrinsic_vector=(0.05, -0.03, 0.02, 0.99, 0.1, -0.05, 0.2))
+    extrinsic = hip.quat_to_mat(ev).cuda()
+    rs = rm.GaussianRasterizationSettings(intrinsic=intr.cuda(), bg=torch.tensor((0.2, 0.4, 0.1), device="cuda"), scale_modifier=1.0,
+                                          sh_degree=3, prefiltered=False, debug=False, clamp_color=True)
+    assert rs._fields == ("intrinsic", "bg", "scale_modifier", "sh_degree", "prefiltered", "debug", "clamp_color")
+    dL = synth.grad_image(W, H)
+    for name, indexed in (("base", False), ("indexed", True)):
+        inp, cam, _ = cases.make_case(name)
+        st = cases.oracle_forward(inp, cam)
+        ref = orc.rasterize_backward(st, dL.numpy())
+        keys = ("means3D", "opacities", "shs", "scales", "rotations") + (("scale_factors",) if indexed else ())
+        leaves = {k: inp[k].cuda().requires_grad_() for k in keys}
+        means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        if indexed:
+            rast = rm.GaussianRasterizerIndexed(rs)
+            color, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                sh_indices=inp["sh_indices"].cuda(), g_indices=inp["g_indices"].cuda(), shs=leaves["shs"],
+                                scales=leaves["scales"], scale_factors=leaves["scale_factors"], rotations=leaves["rotations"],
+                                extrinsic=extrinsic)
+        else:
+            rast = rm.GaussianRasterizer(rs)
+            color, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], shs=leaves["shs"],
+                                scales=leaves["scales"], rotations=leaves["rotations"], extrinsic=extrinsic)
+        assert rast.markVisible(leaves["means3D"], extrinsic).all()
+        (color * dL.cuda()).sum().backward()
+        np.testing.assert_array_equal(radii.cpu().numpy(), st.radii)
+        assert gpu_util.psnr(color.detach().cpu().numpy(), st.out_color) >= 80.0
+        pairs = dict(means3D="dL_dmeans3D", opacities="dL_dopacity", shs="dL_dsh", scales="dL_dscales", rotations="dL_drotations")
+        if indexed:
+            pairs["scale_factors"] = "dL_dscale_factors"
+        for k, r in pairs.items():
+            assert gpu_util.rel_inf(leaves[k].grad.cpu().numpy(), ref[r].reshape(leaves[k].shape)) <= 1e-4, (name, k)
+    with pytest.raises(RuntimeError, match="4x4"):
+        rm.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], shs=inp["shs"].cuda(),
+                                  scales=inp["scales"].cuda()[:1], rotations=inp["rotations"].cuda()[:1], extrinsic=ev.cuda())
+    saved = {k: sys.modules.get(k) for k in ("diff_gaussian_rasterization", "diff_gaussian_rasterization_camera",
+                                             "diff_gaussian_rasterization_no_camera", "weighted_distance", "weighted_distance._C")}
+    try:
+        c3dgs_amd.install_as_reference_modules()
+        import diff_gaussian_rasterization as a
+        import diff_gaussian_rasterization_camera as b
+        import diff_gaussian_rasterization_no_camera as c
+        assert a is rm and b is rm and c is c3dgs_amd.rasterizer
+        assert "extrinsic_vector" in c.GaussianRasterizationSettings._fields and "extrinsic_vector" not in a.GaussianRasterizationSettings._fields
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

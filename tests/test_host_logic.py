@@ -325,3 +325,22 @@ def test_vq_features_host_logic_replays_the_reference_from_a_seed_alone():
                              init_rand=fx["init_rand"], ops=OracleOps)
     np.testing.assert_allclose(cb.numpy(), fx["codebook"], rtol=1e-4, atol=2e-7)
     assert (idx.numpy() == fx["indices"]).mean() >= 0.999
+
+
+def test_matrix_pose_camera_setup_vs_reference_golden():
+    """The 4x4-`extrinsic` path of camera_matrices (the sibling packages' API, diff_gaussian_rasterization/__init__.py:129-135)
+    against tests/golden/camera.npz: `extrinsic @ getProjectionMatrix(intrinsic)` and `extrinsic.inverse()[3, :3]` are the
+    reference's own torch operations: the product reproduces the golden bit for bit on CPU tensors, the inverse to a few ulps."""
+    from c3dgs_amd import rasterizer_matrix as rm
+    d = np.load(os.path.join(G, "camera.npz"), allow_pickle=False)
+    for k in range(d["extrinsic_vector"].shape[0]):
+        intr, extrinsic = torch.from_numpy(d["intrinsic"][k]), torch.from_numpy(d["view"][k])
+        view, proj, campos, tfx, tfy, H, W = rz.camera_matrices(intr, extrinsic, "cpu")
+        np.testing.assert_array_equal(view.numpy().view(np.uint32), d["view"][k].view(np.uint32))
+        np.testing.assert_array_equal(proj.numpy().view(np.uint32), d["proj"][k].view(np.uint32))
+        # (the LU inverse sees a contiguous copy here, a transposed view in the generator: a few ulps)
+        np.testing.assert_allclose(campos.numpy(), d["campos"][k], rtol=2e-6, atol=1e-6 * max(np.abs(d["campos"][k]).max(), 1.0))
+        assert (tfx, tfy, H, W) == (d["scalars"][k, 0], d["scalars"][k, 1], int(d["scalars"][k, 2]), int(d["scalars"][k, 3]))
+    assert rm.GaussianRasterizationSettings._fields == ("intrinsic", "bg", "scale_modifier", "sh_degree", "prefiltered", "debug", "clamp_color")
+    with pytest.raises(RuntimeError, match="4x4"):
+        rz.camera_matrices(torch.from_numpy(d["intrinsic"][0]), torch.zeros(3, 4), "cpu")
