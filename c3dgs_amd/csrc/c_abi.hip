@@ -178,7 +178,7 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     const BinPtrs b = bin_ptrs(bin_base, R, W, H);
 
     if (R > 0) {
-        { StageTimer t_(ST_DUPLICATE, s); launch_duplicate_with_keys(P, g, b, gx, s); } // K5
+        { StageTimer t_(ST_DUPLICATE, s); launch_duplicate_with_keys(P, g, b, gx, sort_err, s); } // K5
         C3DGS_STAGE("duplicate_with_keys", p.debug, s);
         const int end_bit = (int)higher_msb((uint32_t)T);                           // tile bits only (rasterizer_impl.cu:298)
         { StageTimer t_(ST_SORT, s);
@@ -186,7 +186,7 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
                                       b.point_list, R, end_bit, s)); }               // K6, binning stage 2
         C3DGS_STAGE("sort", p.debug, s);
         if (p.debug && onesweep_timed_out(s)) return fail(C3DGS_E_HIP, "tile sort: look-back timed out");
-        { StageTimer t_(ST_RANGES, s); launch_identify_ranges(R, b.keys_sorted, img.ranges, s); } // K8
+        { StageTimer t_(ST_RANGES, s); launch_identify_ranges(R, b.keys_sorted, img.ranges, sort_err, s); } // K8
         C3DGS_STAGE("identify_ranges", p.debug, s);
     }
     { StageTimer t_(ST_RENDER_FWD, s);

@@ -147,8 +147,8 @@ void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t
 void launch_pack_codebook(const c3dgs_raster_params& p, float4* gtab, hipStream_t s);
 void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, const uint32_t* sort_err, hipStream_t s);
 void launch_depth_order_scan(int P, const GeomPtrs& g, hipStream_t s);   // block totals of tiles_sorted -> depth_base[]
-void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, hipStream_t s);
-void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, hipStream_t s);
+void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, const uint32_t* sort_err, hipStream_t s);
+void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, const uint32_t* sort_err, hipStream_t s);
 // binning.hip
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
                           uint32_t* vout, int P, const uint2* rects, uint2* rects_sorted, hipStream_t s);

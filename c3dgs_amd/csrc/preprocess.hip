@@ -403,8 +403,11 @@ block_totals_kernel(int n, const uint2* __restrict__ rects_sorted, uint32_t* __r
 __global__ void __launch_bounds__(256)
 duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint2* __restrict__ rects_sorted,
                            const uint32_t* __restrict__ depth_base, uint16_t* __restrict__ keys, uint32_t* __restrict__ values,
-                           int grid_x)
+                           int grid_x, const uint32_t* __restrict__ sort_err)
 {
+    // a depth sort whose look-back gave up (radix_sort.hip) left positions of `order` / `rects_sorted` unwritten: their stale
+    // contents would be emission offsets -> never dereference them (the image is poisoned by render_forward, the host reports)
+    if (*sort_err) return;
     __shared__ uint32_t s_end[256];      // inclusive emission offset of each of the block's Gaussians
     __shared__ uint32_t s_id[256];
     __shared__ uint2 s_rect[256];
@@ -504,17 +507,20 @@ void launch_depth_order_scan(int P, const GeomPtrs& g, hipStream_t s)
     scan_blocks_kernel<<<1, 1024, 0, s>>>(nb, g.depth_base, nullptr);
 }
 
-void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, hipStream_t s)
+void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, const uint32_t* sort_err, hipStream_t s)
 {
     if (P <= 0) return;
     duplicate_with_keys_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.depth_order, g.sorted_offsets, g.depth_base, b.keys_unsorted,
-                                                               b.values_unsorted, grid_x);
+                                                               b.values_unsorted, grid_x, sort_err);
 }
 
 // ---- K8: reference rasterizer_impl.cu:116-138 (ranges pre-zeroed by the caller, :308)
 __global__ void __launch_bounds__(256)
-identify_ranges_kernel(int L, const uint16_t* __restrict__ keys, uint2* __restrict__ ranges)
+identify_ranges_kernel(int L, const uint16_t* __restrict__ keys, uint2* __restrict__ ranges, const uint32_t* __restrict__ sort_err)
 {
+    // after a sort time-out the "sorted" keys are stale memory: used as tile numbers they would index past `ranges`. The ranges
+    // stay all-zero instead, so render_forward walks no list at all (and returns its NaN image)
+    if (*sort_err) return;
     // eight sorted keys per thread (one 16-byte load + the key in front of them): the buffer is 256-byte aligned and
     // padded, so the last thread's load stays inside it
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -538,11 +544,11 @@ identify_ranges_kernel(int L, const uint16_t* __restrict__ keys, uint2* __restri
     }
 }
 
-void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, hipStream_t s)
+void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, const uint32_t* sort_err, hipStream_t s)
 {
     if (R <= 0) return;
     const int threads = (R + 7) / 8;
-    identify_ranges_kernel<<<(threads + 255) / 256, 256, 0, s>>>(R, keys_sorted, ranges);
+    identify_ranges_kernel<<<(threads + 255) / 256, 256, 0, s>>>(R, keys_sorted, ranges, sort_err);
 }
 
 } // namespace c3dgs

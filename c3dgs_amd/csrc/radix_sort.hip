@@ -26,22 +26,20 @@ namespace c3dgs {
 
 constexpr int OS_RADIX = 256;
 // tile shape per key width (measured): u16 keys 8192-item tiles, 1024 threads x 8 items; u32 keys C3DGS_OS_TILE32 items with
-// C3DGS_OS_BLOCK32 threads (82 KB of LDS would allow only one 1024-thread workgroup per CU)
+// C3DGS_OS_BLOCK32 threads (82 KB of LDS would allow only one 1024-thread workgroup per CU); only the u32 shape is a build knob
 #ifndef C3DGS_OS_TILE32
 #define C3DGS_OS_TILE32 12288   // round 2 (tools/ablate_sort2.sh, 3M keys): 8192 x 512 0.205 ms, 12288 x 512 0.191, 16384 x 512 0.209, 16384 x 1024 0.194
 #endif
 #ifndef C3DGS_OS_BLOCK32
 #define C3DGS_OS_BLOCK32 512
 #endif
-#ifndef C3DGS_OS_TILE16
-#define C3DGS_OS_TILE16 8192    // 16.4 M (u16, u32) pairs: 8192 x 1024 0.215 ms, 12288 x 1024 0.243, 16384 x 1024 0.225
-#endif
-#ifndef C3DGS_OS_BLOCK16
-#define C3DGS_OS_BLOCK16 1024
-#endif
+// u16 keys: fixed shape. os_tile_hist_kernel (the look-back-free first pass) counts the SAME tiles with one 16-byte load of
+// 8 keys per thread, so tile = 8 x 1024 is not a build knob (measured alternatives before that pre-pass existed, 16.4 M
+// (u16, u32) pairs: 8192 x 1024 0.215 ms, 12288 x 1024 0.243, 16384 x 1024 0.225)
+constexpr int OS_TILE16 = 8192, OS_BLOCK16 = 1024;
 template <class K> struct OsShape {
-    static constexpr int TILE = sizeof(K) == 2 ? C3DGS_OS_TILE16 : C3DGS_OS_TILE32;
-    static constexpr int BLOCK = sizeof(K) == 2 ? C3DGS_OS_BLOCK16 : C3DGS_OS_BLOCK32;
+    static constexpr int TILE = sizeof(K) == 2 ? OS_TILE16 : C3DGS_OS_TILE32;
+    static constexpr int BLOCK = sizeof(K) == 2 ? OS_BLOCK16 : C3DGS_OS_BLOCK32;
     static constexpr int IPT = TILE / BLOCK;
 };
 constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_PRE = 2u << 30, OS_CNT_MASK = (1u << 30) - 1;

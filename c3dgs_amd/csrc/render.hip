@@ -217,7 +217,12 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
     if (tid < 2) { s_ab[tid][BATCH][0] = make_float4(0, 0, 0, 0); s_ab[tid][BATCH][1] = make_float4(0, 0, 0, 0); s_c[tid][BATCH] = 0.f; }
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
-    const uint2 range = ranges[tile];
+    // A sort whose look-back timed out (radix_sort.hip) leaves positions of the point list nobody wrote: their stale contents
+    // must never be used as Gaussian ids. duplicate_with_keys / identify_ranges bail out on the same word (the ranges then stay
+    // empty); a time-out of the LAST digit pass is caught here: the tile walks nothing and the image is NaN, not a plausible wrong
+    // one. (wave-uniform scalar load)
+    const bool poisoned = *sort_err != 0u;
+    const uint2 range = poisoned ? make_uint2(0u, 0u) : ranges[tile];
     const int n = (int)(range.y - range.x);
     const int rounds = (n + BATCH - 1) / BATCH;
 
@@ -313,8 +318,7 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
         const size_t pix = (size_t)W * py + px, HW = (size_t)H * W;
         final_T[pix] = Tr;
         n_contrib[pix] = last_contributor;
-        // a sort whose look-back timed out (radix_sort.hip) leaves a mis-ordered list: return NaN, not a plausible image
-        const float poison = *sort_err ? __uint_as_float(0x7fc00000u) : 0.f;
+        const float poison = poisoned ? __uint_as_float(0x7fc00000u) : 0.f;
         out_color[pix] = fmaf(Tr, bg[0], C0) + poison;
         out_color[HW + pix] = fmaf(Tr, bg[1], C1) + poison;
         out_color[2 * HW + pix] = fmaf(Tr, bg[2], C2) + poison;

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Tile shapes of both onesweep sorts as build variants (C3DGS_SORT_FLAGS); per variant: the sort tests, then the bench's stage times.
-# VARIANTS="-DC3DGS_OS_TILE16=16384,-DC3DGS_OS_BLOCK16=1024 ..." bash tools/ablate_sort2.sh
+# Tile shape of the depth-key onesweep sort as build variants (C3DGS_SORT_FLAGS); per variant: the sort tests, then the bench stage times.
+# VARIANTS="-DC3DGS_OS_TILE32=16384,-DC3DGS_OS_BLOCK32=1024 -DC3DGS_OS_TILE32=8192 ..." bash tools/ablate_sort2.sh   (the u16 tile-key sort has a fixed 8192 x 1024 shape)
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 for v in ${VARIANTS}; do
   touch c3dgs_amd/csrc/radix_sort.hip
