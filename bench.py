@@ -21,6 +21,11 @@ Extra objects on the same JSON line:
   parity        HIP vs oracle on THIS workload at full size (integers equal, PSNR, gradient rel-inf; tests/fullsize.py),
                 reusing the oracle view the cpu_baseline leg computes (N = 1 only)
   roofline_blend  the roofline object of BOTH blend kernels (render_forward, render_backward)
+  sizes         the other sizes / shapes BASELINE.json's metric names, timed in this same invocation: configs[1] = 1M forward-only
+                (non-indexed and indexed), 1M and 6M fwd+bwd with the headline's step shape; each with P / V / R
+  heavy_tail    robustness (timing only): the 3M scene with scale = exp(N(log 0.009, 1.2^2)) -- R/P, deepest tile, stage times
+  vq.slice_step_ms  one rank's Lloyd step (draw -> update, no collective) on a 2^15 / 2^16-point slice of the 2^18 batch
+  vq.cov        config 4's covariance codebook loop (D = 6, K = 2048, 2^20-point batches), HBM-bytes roofline per SURVEY 8(d)
   ranks_seen    all-reduce of ones over the job's ranks (must equal n_gpus)
   vq            sensitivity-weighted VQ Lloyd steps/s on config 4's colour shape THROUGH c3dgs_amd.vq_features(group=...)
                 itself (batch draws, collectives and EMA update included), sharded over the N ranks (RCCL), its final
@@ -404,6 +409,25 @@ def main():
     except Exception as e:
         out["postvq_index_layout"] = {"error": repr(e)}
 
+    # ---- the other sizes / shapes of BASELINE.json's metric (1M forward-only = configs[1]; 1M / 6M fwd+bwd) and a heavy-tailed
+    # scene (robustness: R / P of real captures), all driver-timed in this same invocation
+    try:
+        if world > 1 or args.no_extras:
+            raise _SkipExtra()
+        out["sizes"] = bench_sizes(c3dgs_amd, _lib, dev, args.steps)
+    except _SkipExtra:
+        pass
+    except Exception as e:
+        out["sizes"] = {"error": repr(e)}
+    try:
+        if world > 1 or args.no_extras:
+            raise _SkipExtra()
+        out["heavy_tail"] = bench_heavy_tail(c3dgs_amd, _lib, dev, args.steps)
+    except _SkipExtra:
+        pass
+    except Exception as e:
+        out["heavy_tail"] = {"error": repr(e)}
+
     # ---- the whole QAT view from the RAW parameters -- getters (activations + FakeQuantize observers +
     # [visible] gathers) + raster + fused loss + backward -- through c3dgs_amd.model.GaussianModel.render (fused glue),
     # next to the reference's composition of the same glue from torch ops / torch.ao modules around the same rasterizer
@@ -435,6 +459,136 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _scene_step(c3dgs_amd, intr, evd, t, dL, dev, indexed, backward):
+    """One view of a scene `t` (device tensors) through the module API: mark_visible + forward (+ backward through autograd),
+    the shape of the headline step()."""
+    rs = c3dgs_amd.GaussianRasterizationSettings(intrinsic=intr, extrinsic_vector=evd, bg=torch.zeros(3, device=dev), scale_modifier=1.0,
+                                                 sh_degree=3, prefiltered=False, debug=False, clamp_color=True)
+    names = ("means3D", "opacities", "shs", "scales", "rotations") + (("scale_factors",) if indexed else ())
+    leaves = {k: (t[k].clone().requires_grad_() if backward else t[k]) for k in names}
+    means2D = torch.zeros_like(t["means3D"], requires_grad=backward)
+    rast = c3dgs_amd.GaussianRasterizerIndexed(rs, optimize_camera=True) if indexed else c3dgs_amd.GaussianRasterizer(rs)
+
+    def fwd():
+        rast.markVisible(leaves["means3D"], extrinsic_vector=evd)
+        if indexed:
+            return rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], sh_indices=t["sh_indices"],
+                        g_indices=t["g_indices"], shs=leaves["shs"], scales=leaves["scales"], scale_factors=leaves["scale_factors"],
+                        rotations=leaves["rotations"], extrinsic_vector=evd)
+        return rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], shs=leaves["shs"],
+                    scales=leaves["scales"], rotations=leaves["rotations"], extrinsic_vector=evd)
+
+    def step():
+        if not backward:
+            with torch.no_grad():
+                return fwd()
+        for v in leaves.values():
+            v.grad = None
+        means2D.grad = None
+        color, radii = fwd()
+        torch.autograd.backward(color, dL)
+        return color, radii
+    return step
+
+
+def _scene_counts(intr, evd, t, dev, indexed, W, H):
+    """(V, R, deepest tile list) of a scene from one forward through the C-level entry point."""
+    import ctypes as C
+    from c3dgs_amd import _lib
+    from c3dgs_amd import rasterizer as rz
+    E = torch.Tensor([])
+    with torch.no_grad():
+        view, proj, campos, tfx, tfy, _, _ = rz.camera_matrices(intr, evd, dev)
+        bg = torch.zeros(3, device=dev)
+        if indexed:
+            o = rz._C.rasterize_gaussians_indexed(bg, t["means3D"], E, t["opacities"], t["scales"], t["scale_factors"], t["rotations"], 1.0, E,
+                                                  view, proj, tfx, tfy, H, W, t["shs"], 3, campos, t["sh_indices"], t["g_indices"], False, False, True)
+        else:
+            o = rz._C.rasterize_gaussians(bg, t["means3D"], E, t["opacities"], t["scales"], t["rotations"], 1.0, E, view, proj, tfx, tfy,
+                                          H, W, t["shs"], 3, campos, False, False, True)
+    il = _lib.ImageLayout()
+    _lib.lib().c3dgs_get_image_layout(W, H, C.byref(il))
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    rg = o[5][il.ranges:il.ranges + 8 * T].view(torch.int32).view(T, 2).to(torch.int64)
+    radii = o[2]
+    return int((radii > 0).sum()), int(o[0]), int((rg[:, 1] - rg[:, 0]).max()), radii
+
+
+def _time_steps(step, steps, warm=3):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    gc0 = _quiesce()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"views_per_s": steps / el, "ms_per_view": 1e3 * el / steps, "steps": steps, "host_gc_ms": round(_GC["ms"] - gc0, 3)}
+
+
+def bench_sizes(c3dgs_amd, _lib, dev, steps, W=1920, H=1080, focal=1200.0):
+    """The other sizes / shapes BASELINE.json's metric names ("1M/3M/6M Gaussians", configs[1] forward-only), driver-timed in the
+    same invocation as the headline: configs[1] = 1M synth-v1 forward only (render.py path), non-indexed and indexed; 1M and 6M
+    fwd+bwd with the headline's step() shape (indexed QAT path). Each with P / V / R."""
+    from tests import synth
+    intr, ev = synth.camera(W, H, focal)
+    evd = ev.to(dev)
+    dL = synth.grad_image(W, H).to(dev)
+    out = {}
+    n = max(5, min(steps, 20))
+    for P in (1_000_000, 6_000_000):
+        sc = synth.scene(P, W, H, focal, seed=1234, sh_degree=3)
+        ix = synth.index_scene(sc)
+        ti = {k: v.to(dev) for k, v in ix.items()}
+        V, R, deep, _ = _scene_counts(intr, evd, ti, dev, True, W, H)
+        tag = f"{P // 1_000_000}M"
+        if P == 1_000_000:
+            tn = {k: v.to(dev) for k, v in sc.items()}
+            Vn, Rn, _, _ = _scene_counts(intr, evd, tn, dev, False, W, H)
+            out["config2_1M_forward_only_non_indexed"] = dict(_time_steps(_scene_step(c3dgs_amd, intr, evd, tn, dL, dev, False, False), n),
+                                                              gaussians=P, visible=Vn, tile_instances=Rn)
+            out["config2_1M_forward_only_indexed"] = dict(_time_steps(_scene_step(c3dgs_amd, intr, evd, ti, dL, dev, True, False), n),
+                                                          gaussians=P, visible=V, tile_instances=R)
+            del tn
+        out[f"{tag}_fwd_bwd_indexed"] = dict(_time_steps(_scene_step(c3dgs_amd, intr, evd, ti, dL, dev, True, True), n),
+                                             gaussians=P, visible=V, tile_instances=R, deepest_tile_list=deep)
+        del ti, sc, ix
+        torch.cuda.empty_cache()
+    return out
+
+
+def bench_heavy_tail(c3dgs_amd, _lib, dev, steps, P=3_000_000, W=1920, H=1080, focal=1200.0):
+    """Robustness line (timing only; parity for screen-filling splats is in tests/test_fuzz_gpu.py): synth-v1 with a HEAVY-TAILED
+    scale distribution, scale = exp(N(log 0.009, 1.2^2)) per axis instead of sigma 0.6 -- a per cent of the splats are tens to
+    hundreds of pixels wide, R / P rises from 5.5 to the 20-50 of real captures, tile lists get thousands deep. Shows that the
+    load-balanced instance emission, the tile sort and the longest-first backward schedule hold up."""
+    from tests import synth
+    intr, ev = synth.camera(W, H, focal)
+    evd = ev.to(dev)
+    dL = synth.grad_image(W, H).to(dev)
+    sc = synth.scene(P, W, H, focal, seed=1234, sh_degree=3, scale_sigma=1.2)
+    ix = synth.index_scene(sc)
+    t = {k: v.to(dev) for k, v in ix.items()}
+    V, R, deep, radii = _scene_counts(intr, evd, t, dev, True, W, H)
+    rq = torch.quantile(radii[radii > 0].float()[:: max(1, V // 1_000_000)], torch.tensor([0.5, 0.9, 0.99, 0.999], device=dev)).tolist()
+    step = _scene_step(c3dgs_amd, intr, evd, t, dL, dev, True, True)
+    res = dict(_time_steps(step, max(3, min(steps, 8)), warm=2), gaussians=P, visible=V, tile_instances=R, instances_per_gaussian=R / P,
+               deepest_tile_list=deep, radius_px_p50_p90_p99_p999=[round(x, 1) for x in rq],
+               scene="synth-v1 with scale = exp(N(log 0.009, 1.2^2)) per axis (heavy tail), indexed QAT path, fwd+bwd")
+    _lib.profile_enable(True)
+    _lib.profile_read()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    st = _lib.profile_read()
+    _lib.profile_enable(False)
+    res["stages_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(st.items(), key=lambda kv: -kv[1][0])}
+    del t, sc, ix
+    torch.cuda.empty_cache()
+    return res
 
 
 def live_pmc_traffic(P, W, H):
@@ -675,12 +829,97 @@ def bench_vq(c3dgs_amd, _lib, dev, rank, world, steps, cpu_baseline):
            "survey_8d": {"achieved": flops / (wd_step_ms * 1e-3) / 1e12 if wd_step_ms else None, "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": flops / (wd_step_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if wd_step_ms else None}}
     del wd_ms
+    # ---- what ONE rank of a sharded run executes per Lloyd step, without the collective: the same 2^18-point batch is drawn, a
+    # 2^15 / 2^16-point slice of it is assigned + accumulated, the update runs -- the fixed per-step part that bounds strong scaling
+    if world == 1:
+        try:
+            out["slice_step_ms"] = {str(n): vq_slice_step(vqm, feats, imp, K, B, n, max(steps, 30), dev) for n in (2 ** 15, 2 ** 16, 2 ** 18)}
+            out["slice_step_ms"]["what"] = ("ms per full Lloyd step (batch draw -> update, no collective) when only the first n points of each "
+                                            "2^18-point batch are this rank's: n = 2^15 / 2^16 = one of 8 / 4 ranks; launches per step: "
+                                            "draws_to_indices, search, exact re-scan, accumulate (+ distance sum), update (+ next split, clears) "
+                                            "= 5 kernels + 1 host->device copy of the raw draws (profiles/r03_vq_step_kernel_trace.txt)")
+        except Exception as e:
+            out["slice_step_ms"] = {"error": repr(e)}
+    # ---- config 4's OTHER codebook: normalised covariances, D = 6, K = 2048, batches of 2^20, scale_normalize (compress_covariance,
+    # compression/vq.py:149-191). Arithmetic intensity too low for the matrix cores to matter: priced against HBM bytes,
+    # assignment N (4 D + 12) + 4 K D per launch (+ the update's B (4 D + 12) + 8 K (D + 1) per step).
+    try:
+        Nc, Dc, Kc, Bc = 4_500_000, 6, 2048, 2 ** 20
+        fc = torch.randn(Nc, Dc, device=dev, generator=g) * 0.1
+        fc[:, [0, 3, 5]] = fc[:, [0, 3, 5]].abs() + 0.2
+        fc = fc / (fc[:, 0] + fc[:, 3] + fc[:, 5])[:, None]
+        ic = torch.rand(Nc, device=dev, generator=g).pow(4)
+
+        def run_cov(n_steps, profile_stage=None):
+            stc = {}
+            if profile_stage:
+                _lib.profile_enable(True, only=profile_stage)
+                _lib.profile_read()
+            vqm.vq_features(fc, ic, Kc, Bc, n_steps, scale_normalize=True, silent=True, group=group, stats=stc)
+            if profile_stage:
+                stc["stage"] = _lib.profile_read().get(profile_stage, (0.0, 0))
+                _lib.profile_enable(False)
+            return stc
+        run_cov(2)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        _quiesce()
+        stc = run_cov(steps)
+        elc = torch.tensor([stc["lloyd_seconds"], stc["final_assignment_seconds"]], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(elc, op=dist.ReduceOp.MAX)
+        profc, finc = run_cov(steps, "weighted_distance")["stage"], run_cov(0, "weighted_distance")["stage"]
+        wdc_ms = (profc[0] - finc[0]) / max(profc[1] - finc[1], 1)
+        bytes_assign = (Bc / world) * (4 * Dc + 12) + 4 * Kc * Dc
+        out["cov"] = {"metric": "vq_lloyd_steps_per_s", "value": steps / float(elc[0]), "unit": "steps/s", "ms_per_step": 1e3 * float(elc[0]) / steps,
+                      "steps": steps, "n_gpus": world,
+                      "config": {"workload": "config 4 covariance: N=4.5M, D=6, K=2048, batch 2^20 per step split over the ranks, "
+                                             "scale_normalize; c3dgs_amd.vq_features end to end", "batch": Bc},
+                      "final_assignment_ms": 1e3 * float(elc[1]), "assign_kernel_ms": wdc_ms,
+                      "roofline": {"bound": "hbm", "kernel": "weighted_distance", "achieved": bytes_assign / (wdc_ms * 1e-3) / 1e9 if wdc_ms else None,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_assign / (wdc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if wdc_ms else None,
+                                   "traffic": None, "alg_bytes_per_launch": bytes_assign,
+                                   "note": "N (4 D + 12) + 4 K D bytes per assignment (SURVEY 8(d)); the search itself is bound by its "
+                                           "2 N K D = 25.8 GFLOP of fp16 split-operand MFMA + top-2 vector work, not by these 38 MB"}}
+        del fc, ic
+    except Exception as e:
+        out["cov"] = {"error": repr(e)}
     if cpu_baseline and rank == 0 and world == 1:
         try:
             out["cpu_baseline"] = vq_cpu_baseline(N, D, K, B)
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
     return out
+
+
+def vq_slice_step(vqm, feats, imp, K, B, n_slice, steps, dev):
+    """The inner loop of c3dgs_amd.vq.vq_features (same objects: _BatchDraws, HipOps.step_sums / step_apply) as ONE rank of a
+    sharded run executes it, minus the all-reduce: batch of B draws, the first n_slice of them assigned and accumulated, update."""
+    N, D = feats.shape
+    model = vqm.VectorQuantize(channels=D, codebook_size=K, decay=0.8).to(dev)
+    model.uniform_init(feats)
+    err = torch.zeros(steps + 8, dtype=torch.float64, device=dev)
+    state = {}
+
+    def loop(n):
+        draws = vqm._BatchDraws(N, B, n, dev)
+        try:
+            for s_ in range(n):
+                batch = draws.next_batch()
+                res = vqm.HipOps.step_sums(state, feats, imp, batch[:n_slice].contiguous(), model.codebook.data, err[s_:s_ + 1])
+                assert res is not None
+                vqm.HipOps.step_apply(state, model.codebook.data, model.entry_importance.data, model.decay, model.eps, False)
+        finally:
+            draws.finish()
+    loop(5)
+    torch.cuda.synchronize()
+    _quiesce()
+    err.zero_()
+    t0 = time.perf_counter()
+    loop(steps)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
 
 
 def vq_cpu_baseline(N, D, K, B):

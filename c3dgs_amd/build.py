@@ -34,6 +34,7 @@ SOURCES = {
     "encode.hip": [],
     "adam.hip": ["-ffp-contract=off"],
     "qat.hip": ["-ffp-contract=off"],
+    "probe.hip": [],            # measurement-only kernels (PMC calibration), see csrc/probe.hip
 }
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gsmath.hpp"),
            os.path.join(HERE, "..", "include", "c3dgs_hip.h")]

@@ -328,6 +328,13 @@ int c3dgs_profile_read(c3dgs_stage_time* out, int capacity)
 }
 int c3dgs_abi_version(void) { return C3DGS_ABI_VERSION; }
 
+int c3dgs_debug_gather_probe(int32_t kind, int64_t n, void* table, const uint32_t* index, uint32_t* out, void* stream)
+{
+    if (n < 0 || !table || !out || (kind != 0 && !index)) return fail(C3DGS_E_INVALID, "debug_gather_probe: bad arguments");
+    if (launch_gather_probe(kind, (size_t)n, table, index, out, (hipStream_t)stream)) return fail(C3DGS_E_INVALID, "debug_gather_probe: kind must be 0..3");
+    return C3DGS_OK;
+}
+
 int c3dgs_debug_lane_counters(uint64_t* out, void* stream)
 {
     if (!out) return fail(C3DGS_E_INVALID, "debug_lane_counters: NULL buffer");
@@ -505,6 +512,48 @@ int c3dgs_vq_sums(int64_t B, int32_t K, int32_t D, const float* x, const float* 
     }
     C3DGS_STAGE("weighted_distance", 0, (hipStream_t)stream);
     return c3dgs_vq_accumulate(B, K, D, x, w, gather, idx, dist, S, dist_sum, stream);
+}
+
+int c3dgs_vq_step_supported(int32_t K, int32_t D, const float* x, const float* codebook, const void* ws, size_t ws_bytes)
+{
+    return (K > 0 && D > 0 && wd_presplit_supported(K, D, x, codebook, ws, ws_bytes)) ? 1 : 0;
+}
+
+int c3dgs_vq_step_sums(int32_t step, int64_t B, int32_t K, int32_t D, const float* x, const float* w, const int64_t* gather,
+                       const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, void* ws, size_t ws_bytes,
+                       void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (step < 0 || B <= 0 || K <= 0 || D <= 0) return fail(C3DGS_E_INVALID, "vq_step_sums: bad sizes");
+    if (!x || !w || !codebook || !dist || !idx || !S || !dist_sum) return fail(C3DGS_E_INVALID, "vq_step_sums: NULL argument");
+    if (!wd_presplit_supported(K, D, x, codebook, ws, ws_bytes))
+        return fail(C3DGS_E_INVALID, "vq_step_sums: shape / scratch not served by the fused step (see c3dgs_vq_step_supported)");
+    if (step == 0) {            // nothing is prepared yet: the classic first half, then arm the scratch for c3dgs_vq_step_apply
+        C3DGS_HIP_TRY(hipMemsetAsync(S, 0, (size_t)K * (D + 1) * sizeof(float), s));
+        C3DGS_HIP_TRY(hipMemsetAsync(dist_sum, 0, sizeof(double), s));
+    }
+    {
+        StageTimer t_(ST_WDIST, s);
+        if (launch_weighted_distance(B, K, D, x, gather, codebook, dist, idx, s, ws, ws_bytes, step == 0 ? -1 : (step & 1)))
+            return fail(C3DGS_E_INVALID, "vq_step_sums: unsupported shape");
+        if (step == 0) launch_vq_seed_words(K, D, ws, s);
+    }
+    C3DGS_STAGE("weighted_distance", 0, s);
+    { StageTimer t_(ST_VQ_ACC, s);
+      launch_vq_accumulate(B, K, D, x, w, gather, idx, dist, S, dist_sum, s, vq_next_absmax_word(K, D, ws, step & 1)); }
+    C3DGS_STAGE("vq_accumulate", 0, s);
+    return C3DGS_OK;
+}
+
+int c3dgs_vq_step_apply(int32_t step, int32_t K, int32_t D, float* S, float* codebook, float* entry_importance, float decay,
+                        float alpha, float eps, int32_t scale_normalize, void* ws, size_t ws_bytes, void* stream)
+{
+    if (step < 0 || K <= 0 || D <= 0 || !S || !codebook || !entry_importance) return fail(C3DGS_E_INVALID, "vq_step_apply: bad arguments");
+    { StageTimer t_(ST_VQ_APPLY, (hipStream_t)stream);
+      if (launch_vq_apply_split(K, D, S, codebook, entry_importance, decay, alpha, eps, scale_normalize, ws, ws_bytes, step & 1, (hipStream_t)stream))
+          return fail(C3DGS_E_INVALID, "vq_step_apply: shape / scratch not served by the fused step (see c3dgs_vq_step_supported)"); }
+    C3DGS_STAGE("vq_apply", 0, (hipStream_t)stream);
+    return C3DGS_OK;
 }
 
 int c3dgs_debug_wd_scores(int64_t N, int32_t C, int32_t K, const float* coefs, const float* codebook, float* scores, void* ws,

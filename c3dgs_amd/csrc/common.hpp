@@ -180,15 +180,22 @@ void launch_backward_preprocess(const c3dgs_raster_params& p, const int32_t* rad
                                 uint32_t* live_slots, const c3dgs_raster_grads& gr, hipStream_t s);
 // vq.hip
 int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const int64_t* gather, const float* codebook,
-                             float* out_dist, int64_t* out_idx, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0);
+                             float* out_dist, int64_t* out_idx, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0, int presplit = -1);
+bool wd_presplit_supported(int C, int K, const float* coefs, const float* codebook, const void* ws, size_t ws_bytes);
+int launch_vq_apply_split(int K, int D, float* S, float* codebook, float* entry_importance, float decay, float alpha, float eps,
+                          int scale_normalize, void* ws, size_t ws_bytes, int parity, hipStream_t s);
+void launch_vq_seed_words(int K, int D, void* ws, hipStream_t s);
+uint32_t* vq_next_absmax_word(int K, int D, void* ws, int parity);
 size_t wd_ws_bytes(int64_t N, int C, int K);
 int launch_wd_debug_scores(int64_t N, int C, int K, const float* coefs, const float* codebook, float* scores, void* ws, size_t ws_bytes,
                            float* out_dist, int64_t* out_idx, hipStream_t s);
 void launch_vq_accumulate(int64_t B, int K, int D, const float* x, const float* w, const int64_t* gather,
-                          const int64_t* idx, const float* dist, float* S, double* dist_sum, hipStream_t s);
+                          const int64_t* idx, const float* dist, float* S, double* dist_sum, hipStream_t s, uint32_t* clear_word = nullptr);
 void launch_vq_apply(int K, int D, const float* S, float* codebook, float* entry_importance, float decay, float alpha,
                      float eps, int scale_normalize, hipStream_t s);
 
+// probe.hip (measurement only)
+int launch_gather_probe(int kind, size_t n, void* table, const uint32_t* index, uint32_t* out, hipStream_t s);
 // encode.hip
 size_t morton_workspace_bytes(int P);
 int run_morton_order(int P, const float* xyz, int64_t* codes_out, int64_t* order_out, void* workspace, hipStream_t s);

@@ -298,7 +298,7 @@ wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
         if (h == 0 && n < N) {
             const float db = nb + xnorm[g], ds = ns + xnorm[g];
             const float margin = 4e-5f * (fabsf(db) + fabsf(ds) + 2.0f * xnorm[g]) + 1e-37f;
-            const bool ambiguous = !(ns - nb > margin);
+            const bool ambiguous = !(ns - nb > margin) || !scale_ok;
             const float* x = coefs + rows[g] * MF_K;
             const float* cb = codebook + (size_t)ni * MF_K;
             float r = 0.f;
@@ -449,7 +449,7 @@ wd_f16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* 
               const float* __restrict__ codebook, const uint4* __restrict__ frag, const float* __restrict__ norms,
               const uint32_t* __restrict__ absmax,
                float* __restrict__ out_dist, int64_t* __restrict__ out_idx, int* __restrict__ flag_list, int flag_cap,
-               float margin_rel, float* __restrict__ scores)
+               float margin_rel, float* __restrict__ scores, const uint32_t* __restrict__ absmax_true = nullptr)
 {
     constexpr int KS = HfShape<MF_K>::KS;
     constexpr int TILE_V = HfShape<MF_K>::TILE_BYTES / 16, SUB_V = HfShape<MF_K>::SUB_BYTES / 16;
@@ -466,6 +466,12 @@ wd_f16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* 
     // B operands: the two pieces of -2 * 2^e * x[n_base + 32 g + i][16 q + 8 h + j], j = 0..7
     const int sexp = wd_scale_exp(*absmax);
     const float sc2 = -2.0f * __builtin_ldexpf(1.0f, sexp), unscale = __builtin_ldexpf(1.0f, -sexp);
+    // Fused Lloyd step (vq_apply_split_kernel): the fragments were scaled with the exponent of the PREVIOUS codebook's largest
+    // magnitude; absmax_true is the current codebook's. The two normally differ by at most one binade. Should the codebook have
+    // grown 16x or shrunk 64x within one EMA step, the split's error model no longer holds: every point is then declared
+    // ambiguous and decided by the exact re-scan (slow, never wrong).
+    bool scale_ok = true;
+    if (absmax_true) { const int drift = sexp - wd_scale_exp(*absmax_true); scale_ok = drift < 4 && drift > -6; }
     f16x8 bh[2][KS], bl[2][KS];
     float xnorm[2];
     int64_t rows[2];
@@ -802,13 +808,20 @@ constexpr float WD_SPLIT_MARGIN = 4e-5f;
 
 // scratch layout of the split search: [fragments][scaled norms][scale word (largest |c| bits), 16 bytes]
 template <int K>
-static void launch_wd_split_codebook(int C, const float* codebook, void* ws, uint4*& frag, float*& norms, uint32_t*& absmax, hipStream_t s)
-{   // the caller has cleared the scale word (it is the last 16 bytes of the split region, directly in front of the list)
+static void wd_split_pointers(int C, void* ws, uint4*& frag, float*& norms, uint32_t*& absmax)
+{
     const int ntiles = (C + MF_CT - 1) / MF_CT;
     const size_t frag_bytes = (size_t)ntiles * HfShape<K>::TILE_BYTES;
     frag = (uint4*)ws;
     norms = (float*)((char*)ws + frag_bytes);
-    absmax = (uint32_t*)(norms + (size_t)ntiles * MF_CT);
+    absmax = (uint32_t*)(norms + (size_t)ntiles * MF_CT);      // 4 words: [0] the scale the fragments were made with; [1], [2]: see vq_apply_split_kernel
+}
+
+template <int K>
+static void launch_wd_split_codebook(int C, const float* codebook, void* ws, uint4*& frag, float*& norms, uint32_t*& absmax, hipStream_t s)
+{   // the caller has cleared the scale word (it is the last 16 bytes of the split region, directly in front of the list)
+    const int ntiles = (C + MF_CT - 1) / MF_CT;
+    wd_split_pointers<K>(C, ws, frag, norms, absmax);
     const size_t n = (size_t)C * K;
     wd_absmax_kernel<<<(unsigned)std::min<size_t>((n + 4095) / 4096, 64), 256, 0, s>>>(n, codebook, absmax);
     const unsigned gs = (unsigned)((ntiles * (MF_CT / 32) * HfShape<K>::KS * 64 + 255) / 256);
@@ -820,8 +833,9 @@ static void launch_wd_split_codebook(int C, const float* codebook, void* ws, uin
 // left holds the list (without a list the flagged points are re-scanned one by one).
 template <int K>
 static void launch_wd_mfma(int64_t N, int C, const float* coefs, const int64_t* gather, const float* codebook, float* out_dist,
-                           int64_t* out_idx, void* ws, size_t ws_bytes, hipStream_t s)
-{
+                           int64_t* out_idx, void* ws, size_t ws_bytes, hipStream_t s, int presplit = -1)
+{   // presplit >= 0 (fused Lloyd step): ws already holds the fragments / norms / scale word of THIS codebook and a cleared list
+    // counter (vq_apply_split_kernel wrote them); presplit = the parity that selects the word with the codebook's true abs-max
     const unsigned g1 = (unsigned)((N + 4 * MF_PTS - 1) / (4 * MF_PTS)), g2 = (unsigned)((N + 63) / 64);
     // fewer than one 4-wave workgroup per CU (256 CUs): let the 4 waves share 64 points and split the codebook instead
     // (measured, K = 4096 x 48: N = 32,768: 267 -> 158 us; N = 65,536: 271 vs 283 us, so the plain kernel from there on;
@@ -838,13 +852,16 @@ static void launch_wd_mfma(int64_t N, int C, const float* coefs, const int64_t* 
     const int flag_cap = flag_list ? (int)std::min<size_t>(rest_bytes / sizeof(int) - 1, (size_t)0x7fffffff) : 0;
     const bool listed = flag_list != nullptr;
     // one fill clears the scale word (last 16 bytes of the split region) and the list's counter behind it
-    if (f16) (void)hipMemsetAsync((char*)ws + sb - 16, 0, 16 + (listed ? std::min<size_t>(rest_bytes, 16) : 0), s);   // up to 32 bytes: one aligned fill (the first list entries are rewritten by the search)
+    if (presplit >= 0 && f16) { }
+    else if (f16) (void)hipMemsetAsync((char*)ws + sb - 16, 0, 16 + (listed ? std::min<size_t>(rest_bytes, 16) : 0), s);   // up to 32 bytes: one aligned fill (the first list entries are rewritten by the search)
     else if (listed) (void)hipMemsetAsync(flag_list, 0, sizeof(int), s);
     if (f16) {
         uint4* frag; float* norms; uint32_t* absmax;
-        launch_wd_split_codebook<K>(C, codebook, ws, frag, norms, absmax, s);
-        if (split) wd_f16_kernel<K, true, false><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, frag, norms, absmax, out_dist, out_idx, flag_list, flag_cap, margin_env, nullptr);
-        else wd_f16_kernel<K, false, false><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, frag, norms, absmax, out_dist, out_idx, flag_list, flag_cap, margin_env, nullptr);
+        const uint32_t* absmax_true = nullptr;
+        if (presplit >= 0) { wd_split_pointers<K>(C, ws, frag, norms, absmax); absmax_true = absmax + 1 + (presplit & 1); }
+        else launch_wd_split_codebook<K>(C, codebook, ws, frag, norms, absmax, s);
+        if (split) wd_f16_kernel<K, true, false><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, frag, norms, absmax, out_dist, out_idx, flag_list, flag_cap, margin_env, nullptr, absmax_true);
+        else wd_f16_kernel<K, false, false><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, frag, norms, absmax, out_dist, out_idx, flag_list, flag_cap, margin_env, nullptr, absmax_true);
     } else if (split) wd_mfma_kernel<K, true><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
     else wd_mfma_kernel<K, false><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
     if (listed) {
@@ -862,10 +879,26 @@ size_t wd_ws_bytes(int64_t N, int C, int K)
     return ((K == 48 || K == 12 || K == 6) ? wd_split_bytes(C, K) : 0) + list;
 }
 
+// can the fused Lloyd step (vq_apply_split_kernel + pre-split search) serve this shape with this scratch?
+bool wd_presplit_supported(int C, int K, const float* coefs, const float* codebook, const void* ws, size_t ws_bytes)
+{
+    static const bool off = getenv("C3DGS_VQ_EXACT_VALU") != nullptr || getenv("C3DGS_VQ_F32_MFMA") != nullptr || getenv("C3DGS_VQ_NO_FUSED_STEP") != nullptr;
+    if (off || !(K == 48 || K == 12 || K == 6) || C < 32 || !ws || (((uintptr_t)ws) & 15)) return false;
+    if ((((uintptr_t)coefs | (uintptr_t)codebook) & (K == 48 ? 15 : 7)) != 0) return false;
+    return ws_bytes >= wd_split_bytes(C, K) + 2 * sizeof(int);
+}
+
 int launch_weighted_distance(int64_t N, int C, int K, const float* coefs, const int64_t* gather, const float* codebook,
-                             float* out_dist, int64_t* out_idx, hipStream_t s, void* ws, size_t ws_bytes)
+                             float* out_dist, int64_t* out_idx, hipStream_t s, void* ws, size_t ws_bytes, int presplit)
 {
     if (N <= 0) return 0;
+    if (presplit >= 0) {
+        if (!wd_presplit_supported(C, K, coefs, codebook, ws, ws_bytes)) return 1;
+        if (K == 48) launch_wd_mfma<48>(N, C, coefs, gather, codebook, out_dist, out_idx, ws, ws_bytes, s, presplit);
+        else if (K == 12) launch_wd_mfma<12>(N, C, coefs, gather, codebook, out_dist, out_idx, ws, ws_bytes, s, presplit);
+        else launch_wd_mfma<6>(N, C, coefs, gather, codebook, out_dist, out_idx, ws, ws_bytes, s, presplit);
+        return 0;
+    }
     const int64_t per_block = (int64_t)WD_BLOCK * WD_PPT;
     const unsigned grid = (unsigned)((N + per_block - 1) / per_block);
     const bool al16 = (((uintptr_t)coefs | (uintptr_t)codebook) & 15) == 0;
@@ -912,10 +945,29 @@ __device__ __forceinline__ int64_t readlane_i64(int64_t v, int l)
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// one double atomic per workgroup (256 threads): wave shuffles, then LDS
+__device__ __forceinline__ void block_add_double(double v, double* out)
+{
+    __shared__ double s_d[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_d[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = (s_d[0] + s_d[1]) + (s_d[2] + s_d[3]);
+        if (t != 0.0) atomicAdd(out, t);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x, const float* __restrict__ w,
-                     const int64_t* __restrict__ gather, const int64_t* __restrict__ idx, float* __restrict__ S)
+                     const int64_t* __restrict__ gather, const int64_t* __restrict__ idx, float* __restrict__ S,
+                     const float* __restrict__ dist, double* __restrict__ dist_sum, uint32_t* __restrict__ clear_word)
 {
+    // housekeeping for the fused Lloyd step (vq_apply_split_kernel): the absmax word the NEXT apply accumulates into
+    if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
+    double dacc = 0.0;                                           // sum of this lane's min distances (vq.py:71), folded in: no launch of its own
     const int D1 = D + 1;
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * 256) >> 6;
@@ -938,6 +990,7 @@ vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x
         const int64_t row = valid ? (gather ? gather[n] : n) : 0;
         const float wn = valid ? w[row] : 0.f;
         const uint32_t id = valid ? (uint32_t)idx[n] : 0u;
+        if (dist && valid) dacc += (double)dist[n];
         unsigned long long peers = __ballot(valid);
         for (int b = 0; b < idx_bits; b++) {
             const bool bit = (id >> b) & 1u;
@@ -1010,6 +1063,7 @@ vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x
             if (tag >= 0 && lane < D1) atomicAdd(S + (size_t)(uint32_t)tag * D1 + lane, s_sum[sl][lane]);
         }
     }
+    if (dist && dist_sum) block_add_double(dacc, dist_sum);
 }
 
 // Small tables (K*(D+1) <= 16 K floats, e.g. the covariance codebook: 2048 x 7 = 56 KB) are accumulated in a
@@ -1019,8 +1073,10 @@ constexpr int VQ_LDS_FLOATS = 16384;
 
 __global__ void __launch_bounds__(256)
 vq_accumulate_lds_kernel(int64_t B, int K, int D, const float* __restrict__ x, const float* __restrict__ w,
-                         const int64_t* __restrict__ gather, const int64_t* __restrict__ idx, float* __restrict__ S)
+                         const int64_t* __restrict__ gather, const int64_t* __restrict__ idx, float* __restrict__ S,
+                         const float* __restrict__ dist, double* __restrict__ dist_sum, uint32_t* __restrict__ clear_word)
 {
+    if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
     __shared__ float s_S[VQ_LDS_FLOATS];
     const int D1 = D + 1, table = K * D1;
     for (int q = threadIdx.x; q < table; q += 256) s_S[q] = 0.f;
@@ -1042,65 +1098,59 @@ vq_accumulate_lds_kernel(int64_t B, int K, int D, const float* __restrict__ x, c
         const float v = s_S[q];
         if (v != 0.f) atomicAdd(S + q, v);
     }
-}
-
-__global__ void __launch_bounds__(256)
-vq_dist_sum_kernel(int64_t B, const float* __restrict__ dist, double* __restrict__ out)
-{
-    __shared__ double s_red[256];
-    double acc = 0.0;
-    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < B; n += (int64_t)gridDim.x * 256) acc += (double)dist[n];
-    s_red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
-        __syncthreads();
+    if (dist && dist_sum) {                                        // the batch's distance sum, folded in (a point slab per workgroup)
+        const int64_t perp = (B + gridDim.x - 1) / gridDim.x, p0 = (int64_t)blockIdx.x * perp, p1 = p0 + perp < B ? p0 + perp : B;
+        double dacc = 0.0;
+        for (int64_t n = p0 + threadIdx.x; n < p1; n += 256) dacc += (double)dist[n];
+        block_add_double(dacc, dist_sum);
     }
-    if (threadIdx.x == 0) atomicAdd(out, s_red[0]);
 }
 
 void launch_vq_accumulate(int64_t B, int K, int D, const float* x, const float* w, const int64_t* gather,
-                          const int64_t* idx, const float* dist, float* S, double* dist_sum, hipStream_t s)
+                          const int64_t* idx, const float* dist, float* S, double* dist_sum, hipStream_t s, uint32_t* clear_word)
 {
     if (B <= 0) return;
     const int64_t total = B * (D + 1);
     if ((int64_t)K * (D + 1) <= VQ_LDS_FLOATS && total >= (int64_t)1 << 16) {
         const unsigned grid = (unsigned)std::min<int64_t>((total + 4095) / 4096, 512);
-        vq_accumulate_lds_kernel<<<grid, 256, 0, s>>>(B, K, D, x, w, gather, idx, S);
+        vq_accumulate_lds_kernel<<<grid, 256, 0, s>>>(B, K, D, x, w, gather, idx, S, dist, dist_sum, clear_word);
     } else {
         int idx_bits = 1;
         while (idx_bits < 32 && ((int64_t)1 << idx_bits) < (int64_t)K) idx_bits++;
         const unsigned grid = (unsigned)std::min<int64_t>((B + 255) / 256, 256 * 16);        // one wave per 64 points
-        vq_accumulate_kernel<<<grid, 256, 0, s>>>(B, D, idx_bits, x, w, gather, idx, S);
-    }
-    if (dist && dist_sum) {
-        // few workgroups: each ends with one double atomic on the same word (1024 of them were most of this kernel's 14 us)
-        const unsigned g2 = (unsigned)std::min<int64_t>((B + 4095) / 4096, 64);
-        vq_dist_sum_kernel<<<g2, 256, 0, s>>>(B, dist, dist_sum);
+        vq_accumulate_kernel<<<grid, 256, 0, s>>>(B, D, idx_bits, x, w, gather, idx, S, dist, dist_sum, clear_word);
     }
 }
 
+// Single-rounded fp32 operations for the update kernels: plain operators, expanded INSIDE a function body that starts with
+// `#pragma clang fp contract(off)`. (The __fmul_rn / __fadd_rn inline functions of this toolchain are plain operators that
+// carry the translation unit's contraction flag with them: the compiler does fuse them into FMAs, differently from kernel
+// to kernel -- found when the fused update kernel disagreed with vq_apply_kernel by one ulp.)
+#define RN_MUL(a, b) ((a) * (b))
+#define RN_ADD(a, b) ((a) + (b))
+#define RN_DIV(a, b) ((a) / (b))
 // ---- part 2: EMA + optional trace normalisation; one thread per codeword row. Every operation is
-// a single rounded fp32 op (__fmul_rn/__fadd_rn/__fdiv_rn) in the order torch evaluates
+// a single rounded fp32 op (RN_* under contract(off)) in the order torch evaluates
 // moving_avg.mul_(decay).add_(new, alpha) so all ranks of a sharded run stay bit-identical.
 __global__ void __launch_bounds__(256)
 vq_apply_kernel(int K, int D, const float* __restrict__ S, float* __restrict__ codebook, float* __restrict__ entry_importance,
                 float decay, float alpha, float eps, int scale_normalize)
 {
+#pragma clang fp contract(off)
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
     const float* srow = S + (size_t)k * (D + 1);
     float* cb = codebook + (size_t)k * D;
     const float aw = srow[D];
-    entry_importance[k] = __fadd_rn(__fmul_rn(entry_importance[k], decay), __fmul_rn(alpha, aw));
-    const float den = __fadd_rn(aw, eps);
+    entry_importance[k] = RN_ADD(RN_MUL(entry_importance[k], decay), RN_MUL(alpha, aw));
+    const float den = RN_ADD(aw, eps);
     for (int d = 0; d < D; d++) {
-        const float nw = __fdiv_rn(srow[d], den);
-        cb[d] = __fadd_rn(__fmul_rn(cb[d], decay), __fmul_rn(alpha, nw));
+        const float nw = RN_DIV(srow[d], den);
+        cb[d] = RN_ADD(RN_MUL(cb[d], decay), RN_MUL(alpha, nw));
     }
     if (scale_normalize && D >= 6) {
-        const float tr = __fadd_rn(__fadd_rn(cb[0], cb[3]), cb[5]);
-        for (int d = 0; d < D; d++) cb[d] = __fdiv_rn(cb[d], tr);
+        const float tr = RN_ADD(RN_ADD(cb[0], cb[3]), cb[5]);
+        for (int d = 0; d < D; d++) cb[d] = RN_DIV(cb[d], tr);
     }
 }
 
@@ -1110,13 +1160,14 @@ __global__ void __launch_bounds__(256)
 vq_apply_elem_kernel(int K, int D, const float* __restrict__ S, float* __restrict__ codebook, float* __restrict__ entry_importance,
                      float decay, float alpha, float eps)
 {
+#pragma clang fp contract(off)
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= K * D) return;
     const int k = e / D, d = e - k * D;
     const float aw = S[(size_t)k * (D + 1) + D];
-    if (d == 0) entry_importance[k] = __fadd_rn(__fmul_rn(entry_importance[k], decay), __fmul_rn(alpha, aw));
-    const float nw = __fdiv_rn(S[(size_t)k * (D + 1) + d], __fadd_rn(aw, eps));
-    codebook[e] = __fadd_rn(__fmul_rn(codebook[e], decay), __fmul_rn(alpha, nw));
+    if (d == 0) entry_importance[k] = RN_ADD(RN_MUL(entry_importance[k], decay), RN_MUL(alpha, aw));
+    const float nw = RN_DIV(S[(size_t)k * (D + 1) + d], RN_ADD(aw, eps));
+    codebook[e] = RN_ADD(RN_MUL(codebook[e], decay), RN_MUL(alpha, nw));
 }
 
 void launch_vq_apply(int K, int D, const float* S, float* codebook, float* entry_importance, float decay, float alpha,
@@ -1127,6 +1178,146 @@ void launch_vq_apply(int K, int D, const float* S, float* codebook, float* entry
         vq_apply_elem_kernel<<<(unsigned)(((int64_t)K * D + 255) / 256), 256, 0, s>>>(K, D, S, codebook, entry_importance, decay, alpha, eps);
     else
         vq_apply_kernel<<<(K + 255) / 256, 256, 0, s>>>(K, D, S, codebook, entry_importance, decay, alpha, eps, scale_normalize);
+}
+
+
+// ---- the Lloyd step's second half for the loop of vq_features, ONE launch: EMA update (the same single-rounded operations as
+// vq_apply_kernel, so ranks and the unfused path stay bit-identical) + everything the NEXT step's search needs, which used to
+// be four more launches per step (clear of S, clear of the list counter + scale word, wd_absmax_kernel,
+// wd_split_codebook_kernel): the new codebook's fp16 split fragments and scaled ||c||^2, S cleared behind its last reader,
+// the list counter cleared. A workgroup owns one 32-codeword sub-tile of the fragment layout.
+// Scale: the fragments need ONE power of two for the whole codebook, i.e. its largest magnitude -- which this launch is only
+// producing. It scales with the exponent of the codebook it READ (words[1 + parity], complete since the previous launch),
+// accumulates the new codebook's abs-max into words[1 + (1 - parity)] (cleared by the accumulate kernel in between) and
+// records the scale it used in words[0]; the search compares the two and falls back to the exact scan if they are far apart.
+template <int MF_K>
+__global__ void __launch_bounds__(256)
+vq_apply_split_kernel(int K, float* __restrict__ S, float* __restrict__ codebook, float* __restrict__ entry_importance, float decay,
+                      float alpha, float eps, int scale_normalize, uint4* __restrict__ frag, float* __restrict__ norms,
+                      uint32_t* __restrict__ words, int parity, int* __restrict__ list_counter)
+{
+#pragma clang fp contract(off)   // the update must be the SAME single-rounded operations as vq_apply_kernel (explicit fmaf stays fused)
+    constexpr int D = MF_K, D1 = MF_K + 1, KS = HfShape<MF_K>::KS;
+    __shared__ float s_cb[32][D + 1];
+    __shared__ float s_tr[32];
+    __shared__ uint32_t s_m[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ts = blockIdx.x, row0 = ts * 32;
+    const uint32_t a_cur = words[1 + parity];
+    const float sc = __builtin_ldexpf(1.0f, wd_scale_exp(a_cur));
+    if (tid < 32) {
+        const int k = row0 + tid;
+        if (k < K) {
+            const float aw = S[(size_t)k * D1 + D];
+            entry_importance[k] = RN_ADD(RN_MUL(entry_importance[k], decay), RN_MUL(alpha, aw));
+        }
+    }
+    for (int e = tid; e < 32 * D; e += 256) {
+        const int r = e / D, d = e - r * D, k = row0 + r;
+        float v = 0.f;
+        if (k < K) {
+            const float aw = S[(size_t)k * D1 + D];
+            const float nw = RN_DIV(S[(size_t)k * D1 + d], RN_ADD(aw, eps));
+            v = RN_ADD(RN_MUL(codebook[(size_t)k * D + d], decay), RN_MUL(alpha, nw));
+        }
+        s_cb[r][d] = v;
+    }
+    __syncthreads();
+    if (scale_normalize && D >= 6) {                             // vq.py:73-77: codebook /= (cb[:,0] + cb[:,3] + cb[:,5])[:, None]
+        if (tid < 32) s_tr[tid] = RN_ADD(RN_ADD(s_cb[tid][0], s_cb[tid][3]), s_cb[tid][5]);
+        __syncthreads();
+        for (int e = tid; e < 32 * D; e += 256) {
+            const int r = e / D, d = e - r * D;
+            if (row0 + r < K) s_cb[r][d] = RN_DIV(s_cb[r][d], s_tr[r]);
+        }
+        __syncthreads();
+    }
+    uint32_t m = 0;
+    for (int e = tid; e < 32 * D; e += 256) {
+        const int r = e / D, d = e - r * D, k = row0 + r;
+        if (k < K) {
+            const float v = s_cb[r][d];
+            codebook[(size_t)k * D + d] = v;
+            const uint32_t b = __float_as_uint(v) & 0x7fffffffu;
+            m = max(m, b <= 0x7f800000u ? b : 0u);               // NaNs do not set the scale (as wd_absmax_kernel)
+        }
+    }
+    for (int e = tid; e < 32 * D1; e += 256) {                   // S is consumed: cleared for the next step's accumulation
+        const int k = row0 + e / D1;
+        if (k < K) S[(size_t)row0 * D1 + e] = 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if (lane == 0) s_m[wave] = m;
+    // scaled ||c||^2 (k-ordered FMA chain, as wd_split_codebook_kernel); rows past K never win
+    if (tid < 32) {
+        float nr = 3.0e38f;
+        if (row0 + tid < K) {
+            nr = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; k++) nr = fmaf(s_cb[tid][k], s_cb[tid][k], nr);
+            nr = (nr * sc) * sc;
+        }
+        norms[row0 + tid] = nr;
+    }
+    // fragments of this sub-tile: [k-step][piece][lane][8 x fp16]
+    for (int t = tid; t < KS * 64; t += 256) {
+        const int fl = t & 63, q = t >> 6;
+        const int r = fl & 31, k0 = 16 * q + 8 * (fl >> 5);
+        union { f16x8 v; uint4 u; } p[HF_PIECES];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float v = (row0 + r < K && k0 + j < D) ? s_cb[r][k0 + j] * sc : 0.f;
+            _Float16 h, l;
+            f16_split2(v, h, l);
+            p[0].v[j] = h; p[1].v[j] = l;
+        }
+#pragma unroll
+        for (int e = 0; e < HF_PIECES; e++) frag[((size_t)(ts * KS + q) * HF_PIECES + e) * 64 + fl] = p[e].u;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        if (m) atomicMax(&words[1 + (1 - parity)], m);
+        if (blockIdx.x == 0) { words[0] = a_cur; if (list_counter) *list_counter = 0; }
+    }
+}
+
+// first half of the fused protocol: make the scratch of a codebook that was split the classic way (absmax kernel: words[0])
+// ready for vq_apply_split_kernel with parity 0: words[1] = words[0] (true abs-max of the current codebook), words[2] = 0
+__global__ void vq_seed_words_kernel(uint32_t* words) { words[1] = words[0]; words[2] = 0u; }
+
+int launch_vq_apply_split(int K, int D, float* S, float* codebook, float* entry_importance, float decay, float alpha, float eps,
+                          int scale_normalize, void* ws, size_t ws_bytes, int parity, hipStream_t s)
+{
+    if (!wd_presplit_supported(K, D, codebook, codebook, ws, ws_bytes)) return 1;
+    const int ntiles = (K + MF_CT - 1) / MF_CT;
+    uint4* frag; float* norms; uint32_t* words;
+    int* list = (int*)((char*)ws + wd_split_bytes(K, D));
+#define C3DGS_VQ_AS(KK) { wd_split_pointers<KK>(K, ws, frag, norms, words);                                              \
+        vq_apply_split_kernel<KK><<<ntiles * (MF_CT / 32), 256, 0, s>>>(K, S, codebook, entry_importance, decay, alpha, eps,    \
+                                                                        scale_normalize, frag, norms, words, parity & 1, list); }
+    if (D == 48) C3DGS_VQ_AS(48) else if (D == 12) C3DGS_VQ_AS(12) else C3DGS_VQ_AS(6)
+#undef C3DGS_VQ_AS
+    return 0;
+}
+
+void launch_vq_seed_words(int K, int D, void* ws, hipStream_t s)
+{
+    uint4* frag; float* norms; uint32_t* words;
+    if (D == 48) wd_split_pointers<48>(K, ws, frag, norms, words);
+    else if (D == 12) wd_split_pointers<12>(K, ws, frag, norms, words);
+    else wd_split_pointers<6>(K, ws, frag, norms, words);
+    vq_seed_words_kernel<<<1, 1, 0, s>>>(words);
+}
+
+uint32_t* vq_next_absmax_word(int K, int D, void* ws, int parity)
+{
+    uint4* frag; float* norms; uint32_t* words;
+    if (D == 48) wd_split_pointers<48>(K, ws, frag, norms, words);
+    else if (D == 12) wd_split_pointers<12>(K, ws, frag, norms, words);
+    else wd_split_pointers<6>(K, ws, frag, norms, words);
+    return words + 1 + (1 - (parity & 1));
 }
 
 } // namespace c3dgs

@@ -126,6 +126,50 @@ class HipOps:
         return dist, S, dsum
 
     @staticmethod
+    def step_sums(state, x, importance, gather, codebook, dsum_out):
+        """First half of a Lloyd step of vq_features' own loop (c3dgs_vq_step_sums): like `sums`, but from the second step on
+        the search finds the codebook already split by the previous `step_apply`, S and the list counter already cleared and
+        the distance sum folded into the accumulation -- 5 launches per step instead of 11. `state`: dict owned by the loop
+        (buffers + the step counter of the protocol). Returns None when the shape is not served (caller uses `sums`)."""
+        L = _lib.lib()
+        K, D = int(codebook.shape[0]), int(x.size(1))
+        B = int(gather.numel()) if gather is not None else int(x.size(0))
+        dev = x.device
+        key = (B, K, D, dev, codebook.data_ptr())
+        if state.get("key") != key:
+            state.clear()
+            state.update(key=key, step=0,
+                         bufs=(torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.int64, device=dev),
+                               torch.empty(K, D + 1, dtype=torch.float32, device=dev),
+                               torch.empty(int(L.c3dgs_weighted_distance_ws_bytes(B, K, D)), dtype=torch.uint8, device=dev)))
+            dist, idx, S, ws = state["bufs"]
+            state["ok"] = bool(B > 0 and x.dtype == torch.float32 and x.is_contiguous() and codebook.is_contiguous()
+                               and L.c3dgs_vq_step_supported(K, D, x.data_ptr(), codebook.data_ptr(), ws.data_ptr(), int(ws.numel())))
+        if not state["ok"]:
+            return None
+        dist, idx, S, ws = state["bufs"]
+        w = importance
+        with torch.cuda.device(dev):
+            rc = L.c3dgs_vq_step_sums(state["step"], B, K, D, x.data_ptr(), w.data_ptr(), gather.data_ptr() if gather is not None else None,
+                                      codebook.data_ptr(), dist.data_ptr(), idx.data_ptr(), S.data_ptr(), dsum_out.data_ptr(),
+                                      ws.data_ptr(), int(ws.numel()), _stream(dev))
+        _lib.check(rc)
+        return dist, S, dsum_out
+
+    @staticmethod
+    def step_apply(state, codebook, entry_importance, decay, eps, scale_normalize):
+        """Second half (c3dgs_vq_step_apply): the EMA update of `apply` + the next step's split codebook / cleared sums."""
+        L = _lib.lib()
+        K, D = codebook.shape
+        _, _, S, ws = state["bufs"]
+        with torch.cuda.device(codebook.device):
+            rc = L.c3dgs_vq_step_apply(state["step"], K, D, S.data_ptr(), codebook.data_ptr(), entry_importance.data_ptr(), float(decay),
+                                       float(1 - decay), float(eps), int(bool(scale_normalize)), ws.data_ptr(), int(ws.numel()),
+                                       _stream(codebook.device))
+        _lib.check(rc)
+        state["step"] += 1
+
+    @staticmethod
     def apply(S, codebook, entry_importance, decay, eps, scale_normalize):
         L = _lib.lib()
         K, D = codebook.shape
@@ -189,6 +233,7 @@ class VectorQuantize(nn.Module):
 # _MT_NEXT / _MT_STATE the int64 view.
 _MT_WORDS, _MT_LEFT, _MT_NEXT, _MT_STATE, _MT_BYTES = 624, 2, 2, 3, 5056
 _FAST_DRAWS = True      # False: every batch through torch.randint itself (what the tests compare the fast path with)
+_FUSED_STEP = True      # False: every Lloyd step through the plain sums / apply pair (what the tests compare the fused step with)
 
 
 _RING_CACHE = {}            # (device, batch size) -> list of idle pinned rings
@@ -339,6 +384,8 @@ def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size:
     err_local = torch.zeros(max(n_steps, 1), dtype=torch.float64, device=dev)       # per-step sums of min distances
     batch_sizes = []
     scratch = {}
+    fused = {}
+    use_fused = _FUSED_STEP and hasattr(vq_model.ops, "step_sums") and feats.is_cuda
     it = range(steps) if batches is None else range(len(batches))
     src_rank = (dist.get_global_rank(pg, 0) if pg is not None else 0) if world > 1 else 0
     if world > 1 and batches is None and not device_rng:
@@ -365,11 +412,24 @@ def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size:
             with torch.no_grad():
                 # the slice's distance sum lands in this step's slot of err_local (reduced ONCE after the loop: the
                 # errors are reporting only); the exchange of the step is ONE in-place all-reduce of S[K, D+1]
-                _, S, _ = vq_model.partial_sums(feats, imp, gather=batch[lo:hi].contiguous(), scratch=scratch,
-                                                dsum_out=err_local[s:s + 1])
-                if world > 1:
-                    dist.all_reduce(S, group=pg)
-                vq_model.apply_sums(S, scale_normalize=scale_normalize)
+                gsl = batch[lo:hi].contiguous()
+                # the loop owns codebook, sums and search scratch between its steps, so the step's second half can prepare the
+                # next step's search (HipOps.step_sums / step_apply: 5 launches per step); other shapes / injected ops: the
+                # plain pair
+                res = (vq_model.ops.step_sums(fused, feats, imp, gsl, vq_model.codebook.data, err_local[s:s + 1])
+                       if use_fused and hi > lo else None)
+                if res is not None:
+                    S = res[1]
+                    if world > 1:
+                        dist.all_reduce(S, group=pg)
+                    vq_model.ops.step_apply(fused, vq_model.codebook.data, vq_model.entry_importance.data, vq_model.decay,
+                                            vq_model.eps, scale_normalize)
+                else:
+                    fused.clear()                                                       # the protocol restarts at step 0
+                    _, S, _ = vq_model.partial_sums(feats, imp, gather=gsl, scratch=scratch, dsum_out=err_local[s:s + 1])
+                    if world > 1:
+                        dist.all_reduce(S, group=pg)
+                    vq_model.apply_sums(S, scale_normalize=scale_normalize)
             batch_sizes.append(B)
     finally:
         if draws is not None:

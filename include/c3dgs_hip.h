@@ -175,6 +175,26 @@ int c3dgs_vq_sums(int64_t B, int32_t K, int32_t D, const float* x, const float* 
                   const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, void* ws, size_t ws_bytes,
                   void* stream);
 
+/* ---- one Lloyd step of the loop of vq_features (compression/vq.py:68-77) in FIVE launches instead of eleven ----
+ * The same two halves as c3dgs_vq_sums / c3dgs_vq_apply, for a loop that is the only writer of codebook, S and ws between its
+ * own steps (step = 0, 1, 2, ... without gaps; ws = c3dgs_weighted_distance_ws_bytes(B, K, D) bytes, 16-byte aligned, kept
+ * across the steps):
+ *   step_sums(0)   = c3dgs_vq_sums (clears, abs-max + fp16 split of the codebook, search, exact re-scan, accumulation) and arms ws;
+ *   step_apply(s)  = c3dgs_vq_apply's update (the same single-rounded operations, bit-identical codebooks) that ALSO leaves what
+ *                    step s+1's search needs: the new codebook's fp16 split fragments and scaled ||c||^2 (scaled with the exponent
+ *                    of the codebook it read; the new abs-max is gathered for the step after), S cleared, the list counter cleared;
+ *   step_sums(s>0) = search + exact re-scan + accumulation only; *dist_sum must be zero on entry (it is added to). The search
+ *                    checks the scale it was given against the codebook's true abs-max and sends every point through the exact
+ *                    re-scan if the codebook grew 16x or shrank 64x within one update.
+ * The min-distance sum (vq.py:71) is folded into the accumulation kernel. Served shapes: D = 48, 12 or 6, K >= 32
+ * (c3dgs_vq_step_supported); a sharded run all-reduces S between the two halves exactly as with the unfused pair. */
+int c3dgs_vq_step_supported(int32_t K, int32_t D, const float* x, const float* codebook, const void* ws, size_t ws_bytes);
+int c3dgs_vq_step_sums(int32_t step, int64_t B, int32_t K, int32_t D, const float* x, const float* w, const int64_t* gather,
+                       const float* codebook, float* dist, int64_t* idx, float* S, double* dist_sum, void* ws, size_t ws_bytes,
+                       void* stream);
+int c3dgs_vq_step_apply(int32_t step, int32_t K, int32_t D, float* S, float* codebook, float* entry_importance, float decay,
+                        float alpha, float eps, int32_t scale_normalize, void* ws, size_t ws_bytes, void* stream);
+
 /* apply: entry_importance = decay*entry_importance + alpha*S[:,D];
  *        codebook = decay*codebook + alpha * S[:, :D] / (S[:,D] + eps)        (ema_inplace, vq.py:45-46)
  * then, if scale_normalize (D>=6): codebook /= (cb[:,0]+cb[:,3]+cb[:,5])[:,None]   (vq.py:73-77). */
@@ -357,6 +377,12 @@ typedef struct c3dgs_image_layout {   /* byte offsets into the image buffer     
 size_t c3dgs_debug_sort_temp_bytes(int32_t key_bytes, int64_t n, int32_t end_bit);
 int c3dgs_debug_sort_pairs(int32_t key_bytes, int64_t n, int32_t end_bit, const void* keys_in, void* keys_out,
                            const uint32_t* values_in, uint32_t* values_out, void* temp, size_t temp_bytes, void* stream);
+
+/* profiling only: access patterns with a KNOWN byte count, for calibrating the rocprofv3 FETCH_SIZE / WRITE_SIZE counters on this
+ * GPU (tools/pmc_calibrate.py -> profiles/r03_pmc_calibration.txt). kind 0: coalesced 16-byte-per-lane read of n x 16 bytes of
+ * `table`; 1: n lanes each read the 48-byte record index[i] (three 16-byte loads); 2: the 192-byte row index[i] (twelve); 3: n
+ * lanes each store nine floats to the 36-byte slot index[i]. `out`: one word, practically never written. */
+int c3dgs_debug_gather_probe(int32_t kind, int64_t n, void* table, const uint32_t* index, uint32_t* out, void* stream);
 
 /* tests / profiling only: lane-efficiency counters of the two blend kernels, accumulated since the last call and cleared by it.
  * out[0..7] forward, out[8..15] backward: { (wave, Gaussian) pairs run, slots incl. list padding, pixel lanes that used the pair,

@@ -407,3 +407,118 @@ def test_sharded_path_runs_on_the_nccl_backend():
     r = subprocess.run([sys.executable, "-c", _NCCL_CHILD], cwd=root, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(port)))
     assert r.returncode == 0 and "NCCL_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("D,K,B,scale_normalize", [(48, 4096, 2 ** 15, False), (48, 512, 3000, False), (6, 2048, 2 ** 17, True),
+                                                   (12, 256, 1000, False)])
+def test_fused_lloyd_step_is_bit_identical_to_the_plain_pair(hip, D, K, B, scale_normalize):
+    """vq_features' loop runs a Lloyd step as c3dgs_vq_step_sums + c3dgs_vq_step_apply (5 launches: the update also splits
+    the new codebook for the next search, clears S and the list counter; the distance sum rides in the accumulation).
+    Same single-rounded update, exact search: codebooks, indices and entry importances must equal the plain
+    c3dgs_vq_sums / c3dgs_vq_apply pair bit for bit (sharded ranks rely on it), the per-step errors to summation order."""
+    from c3dgs_amd import vq as vqm
+    g = torch.Generator().manual_seed(100 + D)
+    N, steps = 50_000, 7
+    f = (torch.randn(N, D, generator=g) * 0.1).float()
+    if scale_normalize:
+        f[:, [0, 3, 5]] = f[:, [0, 3, 5]].abs() + 0.2
+    imp = torch.rand(N, generator=g).pow(4).float()
+    init = torch.rand(K, D, generator=g)
+    batches = [torch.randint(0, N, (B,), generator=g) for _ in range(steps)]
+    out = {}
+    for fused in (True, False):
+        vqm._FUSED_STEP = fused
+        try:
+            cb, idx, errs = hip.vq_features(f.cuda(), imp.cuda(), K, B, steps, batches=batches, init_rand=init, silent=True,
+                                            scale_normalize=scale_normalize, return_errors=True)
+        finally:
+            vqm._FUSED_STEP = True
+        out[fused] = (cb.cpu().numpy(), idx.cpu().numpy(), np.array(errs))
+    # (the sums are float atomics: two runs of the SAME path differ by summation order too, so bitwise equality of whole loops is
+    # not defined; the update's bit-identity on identical sums is asserted in test_fused_step_protocol_step_by_step)
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-5, atol=1e-7)
+    assert (out[True][1] == out[False][1]).mean() >= 0.999
+    np.testing.assert_allclose(out[True][2], out[False][2], rtol=1e-5)
+
+
+@pytest.mark.parametrize("D,K,B,scale_normalize", [(48, 512, 4096, False), (6, 2048, 70_000, True), (12, 100, 999, False)])
+def test_fused_step_protocol_step_by_step(hip, orc, D, K, B, scale_normalize):
+    """c3dgs_vq_step_sums / c3dgs_vq_step_apply called directly, four steps: every step's distances and indices equal the
+    oracle's on the codebook of that step bit for bit (the search ran on fragments the PREVIOUS update produced), the
+    distance sum equals the float64 sum of the distances, and the update applied to the step's S equals c3dgs_vq_apply on a
+    copy of the same S / codebook / entry importance bit for bit (the same single-rounded operations; compression/vq.py:31-35,
+    73-77) while leaving S cleared."""
+    import ctypes as C
+    from c3dgs_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(19 + D)
+    x = (torch.randn(B, D, generator=g) * 0.1).float()
+    if scale_normalize:
+        x[:, [0, 3, 5]] = x[:, [0, 3, 5]].abs() + 0.2
+    x = x.cuda()
+    w = (torch.rand(B, generator=g) + 0.1).float().cuda()
+    cb = x[torch.randperm(B, generator=g)[:K].cuda()].clone().contiguous()
+    ent = torch.zeros(K, device="cuda")
+    dist, idx = torch.empty(B, device="cuda"), torch.empty(B, dtype=torch.int64, device="cuda")
+    S = torch.empty(K, D + 1, device="cuda")
+    dsum = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ws = torch.empty(int(L.c3dgs_weighted_distance_ws_bytes(B, K, D)), dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.c3dgs_vq_step_supported(K, D, x.data_ptr(), cb.data_ptr(), ws.data_ptr(), int(ws.numel())) == 1
+    for step in range(4):
+        cb_before = cb.clone()
+        _lib.check(L.c3dgs_vq_step_sums(step, B, K, D, x.data_ptr(), w.data_ptr(), None, cb.data_ptr(), dist.data_ptr(), idx.data_ptr(),
+                                        S.data_ptr(), dsum[step:step + 1].data_ptr(), ws.data_ptr(), int(ws.numel()), st))
+        d_ref, i_ref = orc.weighted_distance(x.cpu().numpy(), cb_before.cpu().numpy())
+        np.testing.assert_array_equal(idx.cpu().numpy(), i_ref)
+        np.testing.assert_array_equal(dist.cpu().numpy().view(np.uint32), d_ref.view(np.uint32))
+        want = float(d_ref.astype(np.float64).sum())
+        assert abs(float(dsum[step]) - want) <= 1e-9 * want
+        S_ref = torch.zeros(K, D + 1, dtype=torch.float64, device="cuda")
+        S_ref.index_add_(0, idx, torch.cat([x.double() * w.double()[:, None], w.double()[:, None]], 1))
+        torch.testing.assert_close(S.double(), S_ref, rtol=2e-5, atol=1e-6)
+        S2, cb2, ent2 = S.clone(), cb.clone(), ent.clone()
+        _lib.check(L.c3dgs_vq_apply(K, D, S2.data_ptr(), cb2.data_ptr(), ent2.data_ptr(), 0.8, 0.2, 1e-5, int(scale_normalize), st))
+        _lib.check(L.c3dgs_vq_step_apply(step, K, D, S.data_ptr(), cb.data_ptr(), ent.data_ptr(), 0.8, 0.2, 1e-5, int(scale_normalize),
+                                         ws.data_ptr(), int(ws.numel()), st))
+        np.testing.assert_array_equal(cb.cpu().numpy().view(np.uint32), cb2.cpu().numpy().view(np.uint32))
+        np.testing.assert_array_equal(ent.cpu().numpy().view(np.uint32), ent2.cpu().numpy().view(np.uint32))
+        assert not S.any()                                            # cleared behind its last reader
+
+
+def test_fused_step_falls_back_to_the_exact_scan_when_the_codebook_collapses(hip, orc):
+    """The fused step scales the next search's fp16 fragments with the exponent of the codebook it READ. A codebook of
+    magnitude ~1e3 updated with decay 0 onto data of magnitude ~0.1 shrinks by 2^13 in one step -- far outside the window the
+    split's error model covers -- so the second search must send every point through the exact re-scan: distances and indices
+    still equal the oracle's bit for bit."""
+    import ctypes as C
+    from c3dgs_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(9)
+    B, K, D = 4096, 512, 48
+    x = (torch.randn(B, D, generator=g) * 0.1).float().cuda()
+    w = (torch.rand(B, generator=g) + 0.1).float().cuda()
+    cb = (torch.randn(K, D, generator=g) * 1000.0).float().cuda()
+    ent = torch.zeros(K, device="cuda")
+    dist, idx = torch.empty(B, device="cuda"), torch.empty(B, dtype=torch.int64, device="cuda")
+    S = torch.empty(K, D + 1, device="cuda")
+    dsum = torch.zeros(2, dtype=torch.float64, device="cuda")
+    ws = torch.empty(int(L.c3dgs_weighted_distance_ws_bytes(B, K, D)), dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.c3dgs_vq_step_supported(K, D, x.data_ptr(), cb.data_ptr(), ws.data_ptr(), int(ws.numel())) == 1
+    for step in range(2):
+        cb_before = cb.cpu().numpy().copy()
+        _lib.check(L.c3dgs_vq_step_sums(step, B, K, D, x.data_ptr(), w.data_ptr(), None, cb.data_ptr(), dist.data_ptr(), idx.data_ptr(),
+                                        S.data_ptr(), dsum[step:step + 1].data_ptr(), ws.data_ptr(), int(ws.numel()), st))
+        d_ref, i_ref = orc.weighted_distance(x.cpu().numpy(), cb_before)
+        np.testing.assert_array_equal(idx.cpu().numpy(), i_ref)
+        np.testing.assert_array_equal(dist.cpu().numpy().view(np.uint32), d_ref.view(np.uint32))
+        assert abs(float(dsum[step]) - float(d_ref.astype(np.float64).sum())) <= 1e-9 * float(d_ref.astype(np.float64).sum())
+        _lib.check(L.c3dgs_vq_step_apply(step, K, D, S.data_ptr(), cb.data_ptr(), ent.data_ptr(), 0.0, 1.0, 1e-5, 0, ws.data_ptr(),
+                                         int(ws.numel()), st))
+        assert not S.any()                                            # cleared behind its last reader
+    assert float(cb.abs().max()) < 10.0                            # the codebook did collapse onto the data's scale
+    # unsupported shapes are refused, not mis-served
+    assert L.c3dgs_vq_step_supported(K, 27, x.data_ptr(), cb.data_ptr(), ws.data_ptr(), int(ws.numel())) == 0
+    assert L.c3dgs_vq_step_sums(0, B, K, 27, x.data_ptr(), w.data_ptr(), None, cb.data_ptr(), dist.data_ptr(), idx.data_ptr(), S.data_ptr(),
+                                dsum.data_ptr(), ws.data_ptr(), int(ws.numel()), st) != 0

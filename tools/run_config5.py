@@ -22,6 +22,13 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--color-steps", type=int, default=100)
 ap.add_argument("--gaussian-steps", type=int, default=800)
+ap.add_argument("--scene", default="opaque", choices=["opaque", "translucent"],
+                help="opaque: synth-v1 as benched (opacity sigmoid(N(-1, 1.5^2))): the 32 cameras never blend 94 %% of it, the reference's "
+                     "zero-importance prune (compression/vq.py:205-211) keeps 0.34M of 6M. translucent: opacity sigmoid(N(-3, 1)): "
+                     "rays go deep, most Gaussians earn a gradient and survive, so the QAT stage runs at config-3 scale")
+ap.add_argument("--oracle-psnr", action="store_true",
+                help="also render camera 0 of the UNCOMPRESSED scene with the CPU oracle (oracle/, test infrastructure) and report the "
+                     "PSNR of the HIP render of the uncompressed and of the compressed model against it")
 ap.add_argument("--out", default="gpurun_out/config5.json")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -47,6 +54,21 @@ class Camera:
 
 
 sc = synth.scene(P, W, H, focal, seed=1234, sh_degree=3)
+if args.scene == "translucent":
+    sc["opacities"] = torch.sigmoid(torch.randn(P, 1, generator=torch.Generator().manual_seed(77)) - 3.0).float()
+oracle_img = None
+if args.oracle_psnr:                                # camera 0 of the uncompressed scene through the CPU oracle (checker only)
+    from oracle import oracle as orc
+    intr0, _ = synth.camera(W, H, focal)
+    h0 = 0.5 * float(torch.linspace(-0.25, 0.25, args.cameras)[0])
+    ev0 = torch.tensor([0.0, math.sin(h0), 0.0, math.cos(h0), 0.0, 0.0, 0.0], dtype=torch.float32)
+    t0 = time.time()
+    st = orc.rasterize_forward(bg=torch.zeros(3).numpy(), means3D=sc["means3D"].numpy(), opacities=sc["opacities"].numpy(),
+                               shs=sc["shs"].numpy(), scales=sc["scales"].numpy(), rotations=sc["rotations"].numpy(), degree=3,
+                               scale_modifier=1.0, prefiltered=False, clamp_color=True, **orc.camera(intr0.numpy(), ev0.numpy()))
+    oracle_img = torch.from_numpy(st.out_color).to(dev)
+    timings["oracle_render_camera0_s"] = time.time() - t0
+    del st
 op = sc["opacities"].clamp(1e-6, 1 - 1e-6)
 gaussians = gm.GaussianModel(3, quantization=True, device=dev)
 gaussians.set_tensors(xyz=sc["means3D"], features_dc=sc["shs"][:, :1], features_rest=sc["shs"][:, 1:],
@@ -59,7 +81,10 @@ cams = [Camera(yaw) for yaw in torch.linspace(-0.25, 0.25, args.cameras).tolist(
 with torch.no_grad():
     for c in cams:                                  # "ground truth" = the uncompressed model's own renders
         c.original_image = gaussians.render(c, pipe, bg)["render"].detach().clone()
-print(f"scene: {P} Gaussians, {len(cams)} cameras at {W}x{H}", flush=True)
+print(f"scene: {args.scene}, {P} Gaussians, {len(cams)} cameras at {W}x{H}", flush=True)
+psnr_oracle = {}
+if oracle_img is not None:      # the uncompressed model's own render (with its FakeQuantize observers) against the oracle's
+    psnr_oracle["uncompressed_hip_vs_oracle_dB"] = float(-10 * torch.log10(((cams[0].original_image - oracle_img) ** 2).mean()))
 
 # ---- sensitivity (compress.py:218)
 t0 = sync()
@@ -78,6 +103,7 @@ with torch.no_grad():
     vqm.compress_gaussians(gaussians, color_importance.amax(-1), gaussian_sensitivity.amax(-1), color_comp, gauss_comp,
                            color_compress_non_dir=True, prune_threshold=0.0, silent=True)
 timings["clustering"] = sync() - t0
+survivors = int(gaussians._xyz.shape[0])
 del color_importance, gaussian_sensitivity
 torch.cuda.empty_cache()
 print("clustering", round(timings["clustering"], 2), "s; codebooks", tuple(gaussians._features_dc.shape), tuple(gaussians._scaling.shape),
@@ -137,7 +163,12 @@ gaussians.save_npz(path, sort_morton=True)
 timings["encode"] = time.time() - t0
 size_mb = os.path.getsize(path) / 1024 ** 2
 raw_mb = P * (3 + 48 + 3 + 4 + 1) * 4 / 1024 ** 2
-res = {"gaussians": P, "cameras": len(cams), "resolution": [W, H], "timings_s": timings,
+if oracle_img is not None:
+    with torch.no_grad():
+        img0 = gaussians.render(cams[0], pipe, bg)["render"]
+    psnr_oracle["compressed_hip_vs_oracle_uncompressed_dB"] = float(-10 * torch.log10(((img0 - oracle_img) ** 2).mean()))
+res = {"scene": args.scene, "gaussians": P, "survivors_of_the_importance_prune": survivors, "cameras": len(cams), "resolution": [W, H],
+       "timings_s": timings, "psnr_vs_oracle_camera0": psnr_oracle,
        "total_with_5000_iterations_s": timings["sensitivity_calculation"] + timings["clustering"] + timings["finetune_5000_extrapolated"] + timings["encode"],
        "payload_MiB": size_mb, "uncompressed_fp32_MiB": raw_mb, "compression_ratio": raw_mb / size_mb,
        "psnr_vs_uncompressed_after_vq_dB": psnr_vq, "psnr_vs_uncompressed_after_finetune_dB": psnr_ft,
