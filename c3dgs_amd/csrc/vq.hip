@@ -298,7 +298,7 @@ wd_mfma_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t*
         if (h == 0 && n < N) {
             const float db = nb + xnorm[g], ds = ns + xnorm[g];
             const float margin = 4e-5f * (fabsf(db) + fabsf(ds) + 2.0f * xnorm[g]) + 1e-37f;
-            const bool ambiguous = !(ns - nb > margin) || !scale_ok;
+            const bool ambiguous = !(ns - nb > margin);
             const float* x = coefs + rows[g] * MF_K;
             const float* cb = codebook + (size_t)ni * MF_K;
             float r = 0.f;
@@ -650,7 +650,7 @@ wd_f16_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t* 
             nb = (nb * unscale) * unscale; ns = (ns * unscale) * unscale;   // exact powers of two
             const float db = nb + xnorm[g], ds = ns + xnorm[g];
             const float margin = margin_rel * (fabsf(db) + fabsf(ds) + 2.0f * xnorm[g]) + 1e-37f;
-            const bool ambiguous = !(ns - nb > margin);
+            const bool ambiguous = !(ns - nb > margin) || !scale_ok;
             ni = min(max(ni, 0), C - 1);                   // a padded row can only come out of NaN / inf scores, which are re-scanned anyway
             const float* x = coefs + rows[g] * MF_K;
             const float* cb = codebook + (size_t)ni * MF_K;
