@@ -2,8 +2,11 @@
 
 Units and corrections (MI355X_MICROARCH.md, section HBM): both counters are in KiB; on gfx950 FETCH_SIZE reports exactly
 1/2 of the bytes of a wide coalesced streaming read (128-B requests tallied at 64 B), so it is DOUBLED here; WRITE_SIZE
-reads exactly for streaming stores and float atomics. Gather-heavy kernels are uncalibrated for the x2 (stated in the
-output as `fetch_x2_applied`)."""
+reads exactly for streaming stores and float atomics.
+Calibrated for THIS code's access patterns in round 3 (tools/pmc_calibrate.sh -> profiles/r03_pmc_calibration.txt): random
+48-byte record gathers and 192-byte row gathers issue 128-byte read requests ONLY (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ), each
+tallied at 64 B, so the x2 is exact for the gather kernels as well (`fetch_calibration` in the output); WRITE_SIZE counts
+32-byte sectors for scattered partial-line stores (reported as is)."""
 import collections
 import csv
 import json
@@ -43,6 +46,7 @@ def summarize(fetch_csv, write_csv):
         fb = 2.0 * 1024.0 * sum(f) / len(f)
         wb = 1024.0 * sum(w) / len(w)
         out[st] = {"hbm_bytes_per_launch": fb + wb, "fetch_bytes": fb, "write_bytes": wb, "fetch_x2_applied": True,
+                   "fetch_calibration": "x2 exact: every read request is a 128-B line tallied at 64 B, streams and gathers alike (profiles/r03_pmc_calibration.txt)",
                    "launches_averaged": len(f)}
     return out
 
