@@ -121,6 +121,7 @@ PROTOTYPES = {
     "c3dgs_fake_quantize": (C.c_int, [C.c_int64, _vp, _vp, C.c_int32, C.c_int32, C.c_float, _vp, _vp, _vp]),
     "c3dgs_fake_quantize_backward": (C.c_int, [C.c_int64, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "c3dgs_debug_lane_counters": (C.c_int, [C.POINTER(C.c_uint64), _vp]),
+    "c3dgs_debug_sort_times": (C.c_int, [C.POINTER(C.c_uint64)]),
     "c3dgs_debug_gather_probe": (C.c_int, [C.c_int32, C.c_int64, _vp, _vp, _vp, _vp]),
     "c3dgs_debug_sort_temp_bytes": (C.c_size_t, [C.c_int32, C.c_int64, C.c_int32]),
     "c3dgs_debug_sort_pairs": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),

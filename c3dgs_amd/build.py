@@ -62,7 +62,9 @@ def _compile(name, extra, verbose):
 # that tests/test_sort_gpu.py::test_sort_timeout_is_not_silent exercises (loaded through C3DGS_LIB_PATH in a child process).
 # "lanes": the blend kernels count how many pixel lanes use each (wave, Gaussian) pair (tools/lane_efficiency.py).
 VARIANTS = {"spin1": {"radix_sort.hip": ["-DC3DGS_OS_SPIN_LIMIT=1u"]},
-            "lanes": {"render.hip": ["-DC3DGS_COUNT_LANES"]}}
+            "lanes": {"render.hip": ["-DC3DGS_COUNT_LANES"]},
+            # "ostime": the digit passes of the onesweep sorts stamp the shader clock at their phase boundaries (tools/sort_phases.py)
+            "ostime": {"radix_sort.hip": ["-DC3DGS_OS_TIMING"]}}
 
 
 def build_variant(name, verbose=False):

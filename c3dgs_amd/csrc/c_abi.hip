@@ -328,6 +328,14 @@ int c3dgs_profile_read(c3dgs_stage_time* out, int capacity)
 }
 int c3dgs_abi_version(void) { return C3DGS_ABI_VERSION; }
 
+int c3dgs_debug_sort_times(uint64_t* out /*[512]*/)
+{
+    unsigned long long v[512];
+    if (!out || os_read_times(v)) return fail(C3DGS_E_INVALID, "debug_sort_times: not a C3DGS_OS_TIMING build");
+    for (int i = 0; i < 512; i++) out[i] = (uint64_t)v[i];
+    return C3DGS_OK;
+}
+
 int c3dgs_debug_gather_probe(int32_t kind, int64_t n, void* table, const uint32_t* index, uint32_t* out, void* stream)
 {
     if (n < 0 || !table || !out || (kind != 0 && !index)) return fail(C3DGS_E_INVALID, "debug_gather_probe: bad arguments");

@@ -165,6 +165,7 @@ hipError_t onesweep_depth_sort(void* temp, size_t temp_bytes, const uint32_t* ki
 hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin, uint32_t* vout,
                               int R, int end_bit, hipStream_t s);
 // render.hip
+int os_read_times(unsigned long long* out512);   // radix_sort.hip, experiment builds with -DC3DGS_OS_TIMING only
 int read_lane_counters(unsigned long long* out16, hipStream_t s);   // render.hip; all zero unless built with -DC3DGS_COUNT_LANES
 void launch_render_forward(int W, int H, const ImgPtrs& img, const uint32_t* point_list, const float4* splat,
                            const float* bg, float* out_color, uint8_t* qmask, const uint32_t* sort_err, hipStream_t s);

@@ -56,6 +56,12 @@ constexpr int OS_MAX_PASSES = 4;
 #endif
 constexpr uint32_t OS_SPIN_LIMIT = C3DGS_OS_SPIN_LIMIT;
 __device__ uint32_t g_os_error;           // zero-initialised at module load; bit 0 = tile-key sort, bit 1 = depth-key sort
+#ifdef C3DGS_OS_TIMING
+__device__ unsigned long long g_os_times[64 * 8];
+#define OS_T(slot) if (tid == 0 && (bid & 3) == 0 && (bid >> 2) < 64) g_os_times[(bid >> 2) * 8 + (slot)] = __builtin_readcyclecounter();
+#else
+#define OS_T(slot)
+#endif
 
 struct OsPlan { int passes; int bits[OS_MAX_PASSES]; };
 
@@ -214,6 +220,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
     for (int q = tid; q < OS_WAVES * OS_RADIX; q += OS_BLOCK) (&s_cnt[0][0])[q] = 0;
     __syncthreads();
     const uint32_t bid = s_bid;
+    OS_T(0)
     const uint32_t block_start = bid * (uint32_t)OS_TILE;
     const uint32_t valid = min((uint32_t)OS_TILE, n - block_start);
 
@@ -227,29 +234,47 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
         key[k] = ok ? kin[idx] : (K)0;
         val[k] = ok ? (vin ? vin[idx] : idx) : 0u;             // no payload array: the payload is the item's index
     }
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    volatile uint32_t* wc = s_cnt[wave];              // other lanes of the wave update these between iterations
+    // ranking: lanes with the same digit find each other with BITS ballots. Written on 32-bit halves with the digit bit as a
+    // 0 / -1 mask so that a bit costs six vector instructions (v_bfe_i32, v_cmp, 2 x v_xnor, 2 x v_and); the obvious
+    // `peers &= bit ? bal : ~bal` compiled to 16 (two compares per bit, a 64-bit select built from v_cndmask + v_lshl_add_u64).
+    // The per-wave digit counters are read and bumped through plain LDS instructions (wavefront-scope relaxed atomics): a
+    // `volatile` pointer made them FLAT loads / stores with system-scope cache bits and a full vmcnt(0) wait each -- two memory
+    // round trips per item, which was most of this loop's time (tools/sort_phases.py: rank loop 47 % of a depth-key pass).
+    const uint32_t lt_lo = lane < 32 ? (1u << lane) - 1u : 0xffffffffu, lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
+#ifdef C3DGS_OS_TIMING
+    if (key[0] == (K)0x12345678 && val[OS_IPT - 1] == 0x87654321u) kout[0] = key[OS_IPT - 1];   // force the loads to complete here
+    asm volatile("s_waitcnt vmcnt(0)");
+#endif
+    OS_T(1)
+    uint32_t* wc = s_cnt[wave];                       // other lanes of the wave update these between iterations
 #pragma unroll
     for (int k = 0; k < OS_IPT; k++) {
         const uint32_t idx = wbase + (uint32_t)k * 64u + lane;
         const bool ok = idx < n;
         const uint32_t d = ((uint32_t)key[k] >> shift) & MASK;
-        unsigned long long peers = __ballot(ok);      // padding lanes of the last tile take no part
+        const unsigned long long okb = __ballot(ok);  // padding lanes of the last tile take no part
+        uint32_t plo = (uint32_t)okb, phi = (uint32_t)(okb >> 32);
 #pragma unroll
         for (int b = 0; b < BITS; b++) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
+            const int sgn = __builtin_amdgcn_sbfe((int)d, b, 1);                      // 0 or -1
+            const unsigned long long bal = __ballot(sgn != 0);
+            plo &= ~((uint32_t)bal ^ (uint32_t)sgn);                                   // bit set: keep bal; clear: keep ~bal
+            phi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)sgn);
         }
         rank[k] = 0;
         if (ok) {
-            const uint32_t before = wc[d];
-            rank[k] = before + (uint32_t)__popcll(peers & lt);
-            if ((peers & lt) == 0) wc[d] = before + (uint32_t)__popcll(peers);
+            const uint32_t before = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const uint32_t below = (uint32_t)__popc(plo & lt_lo) + (uint32_t)__popc(phi & lt_hi);
+            rank[k] = before + below;
+            if (below == 0) __hip_atomic_store(&wc[d], before + (uint32_t)__popc(plo) + (uint32_t)__popc(phi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    OS_T(2)
     __syncthreads();
+    OS_T(3)
     // thread d (< 256): the tile's count of digit d, exclusive prefixes across the waves, then across the digits
     uint32_t tot = 0;
     if (tid < OS_RADIX) {
@@ -283,6 +308,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
             os_store(my, OS_FLAG_PRE | (pre + tot));
         }
     }
+    OS_T(4)
     // exclusive scan of the global digit histogram by the same 256 threads
     const uint32_t h = tid < OS_RADIX ? hist[tid] : 0u;
     uint32_t hincl = h;
@@ -296,6 +322,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
         for (int w = 0; w < wave; w++) off += s_wtot[w];
         s_gbase[tid] = (int32_t)(off + hincl - h + pre) - (int32_t)start;
     }
+    OS_T(5)
     // stable reorder of the tile through LDS
 #pragma unroll
     for (int k = 0; k < OS_IPT; k++) {
@@ -308,6 +335,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
         }
     }
     __syncthreads();
+    OS_T(6)
 #pragma unroll
     for (int m = 0; m < OS_IPT; m++) {
         const uint32_t p = (uint32_t)tid + (uint32_t)m * OS_BLOCK;
@@ -321,6 +349,10 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
             if (gather_src) gather_dst[g] = gather_src[vv];     // last pass of the depth sort: per-Gaussian data in sorted order
         }
     }
+#ifdef C3DGS_OS_TIMING
+    asm volatile("s_waitcnt vmcnt(0)");
+#endif
+    OS_T(7)
 }
 
 template <class K, bool PRE>
@@ -396,6 +428,15 @@ static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, 
     }
     return hipGetLastError();
 }
+
+#ifdef C3DGS_OS_TIMING
+int os_read_times(unsigned long long* out512)
+{
+    return hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_os_times), sizeof(unsigned long long) * 512) != hipSuccess;
+}
+#else
+int os_read_times(unsigned long long*) { return 1; }
+#endif
 
 // address of the current device's sticky error word (cached per device; one process per GPU is the normal case)
 uint32_t* onesweep_error_word()

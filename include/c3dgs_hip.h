@@ -378,6 +378,10 @@ size_t c3dgs_debug_sort_temp_bytes(int32_t key_bytes, int64_t n, int32_t end_bit
 int c3dgs_debug_sort_pairs(int32_t key_bytes, int64_t n, int32_t end_bit, const void* keys_in, void* keys_out,
                            const uint32_t* values_in, uint32_t* values_out, void* temp, size_t temp_bytes, void* stream);
 
+/* experiment builds only (radix_sort.hip compiled with -DC3DGS_OS_TIMING): phase time stamps of the last digit pass, 64 tiles x 8
+ * stamps of the shader clock; fails in the product build. */
+int c3dgs_debug_sort_times(uint64_t* out /*[512], host*/);
+
 /* profiling only: access patterns with a KNOWN byte count, for calibrating the rocprofv3 FETCH_SIZE / WRITE_SIZE counters on this
  * GPU (tools/pmc_calibrate.py -> profiles/r03_pmc_calibration.txt). kind 0: coalesced 16-byte-per-lane read of n x 16 bytes of
  * `table`; 1: n lanes each read the 48-byte record index[i] (three 16-byte loads); 2: the 192-byte row index[i] (twelve); 3: n
