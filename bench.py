@@ -837,7 +837,7 @@ def bench_vq(c3dgs_amd, _lib, dev, rank, world, steps, cpu_baseline):
             out["slice_step_ms"]["what"] = ("ms per full Lloyd step (batch draw -> update, no collective) when only the first n points of each "
                                             "2^18-point batch are this rank's: n = 2^15 / 2^16 = one of 8 / 4 ranks; launches per step: "
                                             "draws_to_indices, search, exact re-scan, accumulate (+ distance sum), update (+ next split, clears) "
-                                            "= 5 kernels + 1 host->device copy of the raw draws (profiles/r03_vq_step_kernel_trace.txt)")
+                                            "= 5 kernels, no copy (the conversion kernel reads the raw draws from page-locked host memory; profiles/r03_vq_step_kernel_trace.txt)")
         except Exception as e:
             out["slice_step_ms"] = {"error": repr(e)}
     # ---- config 4's OTHER codebook: normalised covariances, D = 6, K = 2048, batches of 2^20, scale_normalize (compress_covariance,
@@ -906,8 +906,8 @@ def vq_slice_step(vqm, feats, imp, K, B, n_slice, steps, dev):
         draws = vqm._BatchDraws(N, B, n, dev)
         try:
             for s_ in range(n):
-                batch = draws.next_batch()
-                res = vqm.HipOps.step_sums(state, feats, imp, batch[:n_slice].contiguous(), model.codebook.data, err[s_:s_ + 1])
+                batch = draws.next_batch(0, n_slice)            # rank 0's slice of the common batch, as vq_features asks for it
+                res = vqm.HipOps.step_sums(state, feats, imp, batch, model.codebook.data, err[s_:s_ + 1])
                 assert res is not None
                 vqm.HipOps.step_apply(state, model.codebook.data, model.entry_importance.data, model.decay, model.eps, False)
         finally:

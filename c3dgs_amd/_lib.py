@@ -101,6 +101,8 @@ PROTOTYPES = {
                                  C.c_int32, C.c_void_p]),
     "c3dgs_mt19937_fill": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.c_int64]),
     "c3dgs_draws_to_indices": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c3dgs_host_buffer_device_address": (C.c_void_p, [C.c_void_p]),
+    "c3dgs_draws_upload": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c3dgs_morton_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "c3dgs_morton_order": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c3dgs_adam_step": (C.c_int, [C.c_int32, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double, _vp]),

@@ -87,4 +87,27 @@ int c3dgs_draws_to_indices(int64_t n, int64_t range, const uint32_t* raw, int64_
     return C3DGS_OK;
 }
 
+/* the device-side address of a page-locked host buffer (hipHostMalloc / torch pin_memory), or NULL if the buffer is not mapped
+ * into the device's address space. With it, c3dgs_draws_to_indices reads the raw words straight from host memory: no copy
+ * operation in the stream at all (a rank's slice of a batch is 128 KB; the copy's launch cost more than its transfer). */
+void* c3dgs_host_buffer_device_address(const void* host_ptr)
+{
+    hipPointerAttribute_t at;
+    if (!host_ptr || hipPointerGetAttributes(&at, host_ptr) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    return at.devicePointer;
+}
+
+/* upload + convert in one call: `n` raw words from (pinned) host memory to `raw_dev`, then out[i] = raw_dev[i] % range */
+int c3dgs_draws_upload(int64_t n, int64_t range, const uint32_t* raw_host, uint32_t* raw_dev, int64_t* out, void* stream)
+{
+    if (n < 0 || range <= 0 || range >= ((int64_t)1 << 32)) return fail(C3DGS_E_INVALID, "draws_upload: range must be in [1, 2^32)");
+    if (n == 0) return C3DGS_OK;
+    if (!raw_host || !raw_dev || !out) return fail(C3DGS_E_INVALID, "draws_upload: bad arguments");
+    C3DGS_HIP_TRY(hipMemcpyAsync(raw_dev, raw_host, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+    draws_to_indices_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(n, (uint32_t)range, raw_dev, out);
+    C3DGS_STAGE("draws_to_indices", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
 } // extern "C"

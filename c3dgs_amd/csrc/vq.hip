@@ -963,8 +963,11 @@ __device__ __forceinline__ void block_add_double(double v, double* out)
 __global__ void __launch_bounds__(256)
 vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x, const float* __restrict__ w,
                      const int64_t* __restrict__ gather, const int64_t* __restrict__ idx, float* __restrict__ S,
-                     const float* __restrict__ dist, double* __restrict__ dist_sum, uint32_t* __restrict__ clear_word)
+                     const float* __restrict__ dist, double* __restrict__ dist_sum, uint32_t* __restrict__ clear_word, int pts)
 {
+    // pts = points per wave and round (64, or 16 for small batches: a rank's 2^15-point slice is only 512 waves of 64 points --
+    // half the chip's SIMDs, each walking its chunk's 49 sweeps of gathers one memory round trip after the other; 16 points
+    // per wave give four times the waves a quarter of the sweeps each)
     // housekeeping for the fused Lloyd step (vq_apply_split_kernel): the absmax word the NEXT apply accumulates into
     if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
     double dacc = 0.0;                                           // sum of this lane's min distances (vq.py:71), folded in: no launch of its own
@@ -984,9 +987,9 @@ vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x
         if (threadIdx.x < SLOTS) s_tag[threadIdx.x] = -1;
     }
     __syncthreads();
-    for (int64_t base = wave_id * 64; base < B; base += n_waves * 64) {
+    for (int64_t base = wave_id * pts; base < B; base += n_waves * pts) {
         const int64_t n = base + lane;
-        const bool valid = n < B;
+        const bool valid = lane < pts && n < B;
         const int64_t row = valid ? (gather ? gather[n] : n) : 0;
         const float wn = valid ? w[row] : 0.f;
         const uint32_t id = valid ? (uint32_t)idx[n] : 0u;
@@ -1007,13 +1010,27 @@ vq_accumulate_kernel(int64_t B, int D, int idx_bits, const float* __restrict__ x
             // The trip count is WAVE-UNIFORM and the shuffles run with every lane active: ds_bpermute returns 0 from a source
             // lane that is masked off, so a lane-dependent loop bound (lanes with e >= total leaving early in the last sweep)
             // lost the contributions of points whose owner lane had left -- ragged tails with (cnt * D1) % 64 in 1..cnt-1.
-            for (int e0 = 0; e0 < total; e0 += 64) {                 // the point's row / weight / codeword come from the lane
-                const int e = e0 + lane;                             // that already holds them (no dependent global loads)
-                const int j = min(e / D1, cnt - 1), c = e - j * D1;
-                const int64_t rj = (int64_t)(((uint64_t)(uint32_t)__shfl((int)row_hi, j) << 32) | (uint32_t)__shfl((int)row_lo, j));
-                const float wj = __shfl(wn, j);
-                const uint32_t idj = (uint32_t)__shfl((int)id, j);
-                if (e < total) atomicAdd(S + (size_t)idj * D1 + c, c < D ? x[rj * D + c] * wj : wj);
+            // Seven sweeps of 64 elements per round (D + 1 = 49 = 7 x 7 for the colour codebook): the element loads of a round
+            // are all issued before its first atomic. With one load per iteration the compiler cannot move a load across the
+            // atomic in front of it, and a wave paid one dependent memory round trip per sweep -- invisible on a 2^18-point
+            // batch (4096 waves hide each other), 41 us of a 2^15-point slice's 128 us of kernels.
+            constexpr int U = 7;
+            for (int e0 = 0; e0 < total; e0 += 64 * U) {             // the point's row / weight / codeword come from the lane
+                float v[U];                                          // that already holds them (no dependent global loads)
+                size_t dst[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int e = e0 + 64 * u + lane;
+                    const int j = min(e / D1, cnt - 1), c = e - j * D1;
+                    const int64_t rj = (int64_t)(((uint64_t)(uint32_t)__shfl((int)row_hi, j) << 32) | (uint32_t)__shfl((int)row_lo, j));
+                    const float wj = __shfl(wn, j);
+                    const uint32_t idj = (uint32_t)__shfl((int)id, j);
+                    dst[u] = (size_t)idj * D1 + c;
+                    v[u] = (e < total && c < D) ? x[rj * D + c] * wj : wj;
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (e0 + 64 * u + lane < total) atomicAdd(S + dst[u], v[u]);
             }
             continue;
         }
@@ -1117,8 +1134,9 @@ void launch_vq_accumulate(int64_t B, int K, int D, const float* x, const float* 
     } else {
         int idx_bits = 1;
         while (idx_bits < 32 && ((int64_t)1 << idx_bits) < (int64_t)K) idx_bits++;
-        const unsigned grid = (unsigned)std::min<int64_t>((B + 255) / 256, 256 * 16);        // one wave per 64 points
-        vq_accumulate_kernel<<<grid, 256, 0, s>>>(B, D, idx_bits, x, w, gather, idx, S, dist, dist_sum, clear_word);
+        const int pts = B <= ((int64_t)1 << 16) ? 16 : 64;                                  // points per wave (see the kernel)
+        const unsigned grid = (unsigned)std::min<int64_t>((B + 4 * pts - 1) / (4 * pts), 256 * 16);
+        vq_accumulate_kernel<<<grid, 256, 0, s>>>(B, D, idx_bits, x, w, gather, idx, S, dist, dist_sum, clear_word, pts);
     }
 }
 

@@ -233,6 +233,7 @@ class VectorQuantize(nn.Module):
 # _MT_NEXT / _MT_STATE the int64 view.
 _MT_WORDS, _MT_LEFT, _MT_NEXT, _MT_STATE, _MT_BYTES = 624, 2, 2, 3, 5056
 _FAST_DRAWS = True      # False: every batch through torch.randint itself (what the tests compare the fast path with)
+_ZERO_COPY_DRAWS = True # False: the raw draws are copied to the device (c3dgs_draws_upload) instead of read in place by the kernel
 _FUSED_STEP = True      # False: every Lloyd step through the plain sums / apply pair (what the tests compare the fused step with)
 
 
@@ -252,8 +253,9 @@ class _BatchDraws:
     """The batch indices of one Lloyd step: exactly the reference's draws, `torch.randint(0, N, [chunk])` on the CPU
     default generator (vq.py:69), i.e. `mt19937() % N` per element. torch's scalar path costs ~2 ns per draw (2 ms for a
     2^20 batch -- more than the step's kernels), so the generator's stream is continued by the library's block-wise
-    MT19937 (csrc/draws.hip) into a ring of pinned buffers as raw 32-bit words, copied at 4 B/draw, and reduced `% N`
-    on the GPU. The advanced state is written back to the torch generator by finish(), so later torch draws are
+    MT19937 (csrc/draws.hip) into a ring of pinned buffers as raw 32-bit words and reduced `% N` on the GPU by a kernel that
+    reads the words straight from the page-locked host buffer (mapped for the device: no copy operation in the stream; a
+    rank of a sharded run converts only its slice of the batch). The advanced state is written back to the torch generator by finish(), so later torch draws are
     unchanged as well. Falls back to torch.randint itself when the state layout is not the expected one or N >= 2^28 (from there on this
     torch consumes two outputs per element).
     device_rng=True draws on the GPU instead: no host work, different numbers."""
@@ -264,6 +266,7 @@ class _BatchDraws:
         device = torch.device(device)
         self.N, self.chunk, self.device, self.device_rng = N, chunk, device, device_rng
         self.key = None
+        self._dev = None
         st = torch.get_rng_state()
         if not _FAST_DRAWS or device_rng or device.type != "cuda" or not (0 < N < 2 ** 28) or st.numel() != _MT_BYTES or chunk <= 0:
             return
@@ -290,6 +293,8 @@ class _BatchDraws:
         self.steps = int(steps)
         self._pool = _fill_pool() if self.steps > 1 else None
         self._pending = None
+        self._dev = None
+        self._mapped = {}
 
     def _fill(self, k, ahead=False):
         host, ev = self.ring[k % self.RING]
@@ -300,25 +305,40 @@ class _BatchDraws:
         _lib.check(_lib.lib().c3dgs_mt19937_fill(self.key.data_ptr(), C.byref(self.left), C.byref(self.next), host.data_ptr(), self.chunk))
         return host, ev
 
-    def next_batch(self):
+    def next_batch(self, lo=0, hi=None):
+        """The next batch's indices [lo, hi) (default: all of them). A rank of a sharded run asks for ITS slice only: the whole
+        batch is drawn (every rank follows the same stream) but only the slice's raw words cross to the device -- 128 KB
+        instead of 1 MB for one of eight ranks of a 2^18-point batch, whose copy the step's first kernel used to wait for.
+        The returned tensor is reused by the next call (consume it in stream order)."""
+        hi = self.chunk if hi is None else hi
         if self.device_rng:
-            return torch.randint(low=0, high=self.N, size=[self.chunk], device=self.device)
+            return torch.randint(low=0, high=self.N, size=[self.chunk], device=self.device)[lo:hi]
         if self.key is None:
-            return torch.randint(low=0, high=self.N, size=[self.chunk]).to(self.device)
+            return torch.randint(low=0, high=self.N, size=[self.chunk])[lo:hi].to(self.device)
         k = self.k
         self.k += 1
         host, ev = self._pending.result() if self._pending is not None else self._fill(k)
         self._pending = None
+        if self._dev is None:            # device-side staging, once per loop: raw words + indices (reused every step, stream-ordered)
+            self._dev = (torch.empty(self.chunk, dtype=torch.int32, device=self.device),
+                         torch.empty(self.chunk, dtype=torch.int64, device=self.device),
+                         torch.cuda.current_stream(self.device).cuda_stream)
+        raw, out, stream = self._dev
         L = _lib.lib()
+        if self._pool is not None and k + 1 < self.steps:
+            # batch k + 1 is filled (ring buffer (k + 1) % RING: another one) while this step's kernels run; submitted BEFORE this
+            # step's launches so that the hand-over to the worker thread does not sit between the conversion kernel and the search
+            self._pending = self._pool.submit(self._fill, k + 1, True)
         with torch.cuda.device(self.device):
-            raw = host.to(self.device, non_blocking=True)
+            mapped = self._mapped.get(host.data_ptr())
+            if mapped is None:           # is the pinned buffer mapped for the device? (once per ring buffer)
+                mapped = self._mapped[host.data_ptr()] = (L.c3dgs_host_buffer_device_address(host.data_ptr()) or 0) if _ZERO_COPY_DRAWS else 0
+            if mapped:                   # the conversion kernel reads the words from host memory itself: no copy in the stream
+                _lib.check(L.c3dgs_draws_to_indices(hi - lo, self.N, mapped + 4 * lo, out.data_ptr(), stream))
+            else:
+                _lib.check(L.c3dgs_draws_upload(hi - lo, self.N, host.data_ptr() + 4 * lo, raw.data_ptr(), out.data_ptr(), stream))
             ev.record()
-            if self._pool is not None and k + 1 < self.steps:
-                self._pending = self._pool.submit(self._fill, k + 1, True)  # after ev.record(): buffer (k + 1) % RING is another one
-            out = torch.empty(self.chunk, dtype=torch.int64, device=self.device)
-            _lib.check(L.c3dgs_draws_to_indices(self.chunk, self.N, raw.data_ptr(), out.data_ptr(),
-                                                torch.cuda.current_stream(self.device).cuda_stream))
-        return out
+        return out[:hi - lo]
 
     def finish(self):
         """Write the advanced generator state back to torch (call once, also on error paths)."""
@@ -403,16 +423,23 @@ def vq_features(features: torch.Tensor, importance: torch.Tensor, codebook_size:
         for s in it:
             if batches is not None:
                 batch = batches[s].to(device=dev, dtype=torch.int64)
-            else:
+                B = int(batch.numel())
+                lo, hi = (rank * B) // world, ((rank + 1) * B) // world
+                batch = batch[lo:hi]
+            elif world > 1 and device_rng:                                          # GPU generators differ per rank
                 batch = draws.next_batch()
-                if world > 1 and device_rng:                                        # GPU generators differ per rank
-                    dist.broadcast(batch, src=src_rank, group=pg)
-            B = int(batch.numel())
-            lo, hi = (rank * B) // world, ((rank + 1) * B) // world
+                dist.broadcast(batch, src=src_rank, group=pg)
+                B = int(batch.numel())
+                lo, hi = (rank * B) // world, ((rank + 1) * B) // world
+                batch = batch[lo:hi]
+            else:
+                B = vq_chunk
+                lo, hi = (rank * B) // world, ((rank + 1) * B) // world
+                batch = draws.next_batch(lo, hi)                                     # this rank's slice of the common batch
             with torch.no_grad():
                 # the slice's distance sum lands in this step's slot of err_local (reduced ONCE after the loop: the
                 # errors are reporting only); the exchange of the step is ONE in-place all-reduce of S[K, D+1]
-                gsl = batch[lo:hi].contiguous()
+                gsl = batch.contiguous()
                 # the loop owns codebook, sums and search scratch between its steps, so the step's second half can prepare the
                 # next step's search (HipOps.step_sums / step_apply: 5 launches per step); other shapes / injected ops: the
                 # plain pair

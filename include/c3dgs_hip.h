@@ -210,6 +210,12 @@ int c3dgs_vq_apply(int32_t K, int32_t D, const float* S, float* codebook, float*
  * for range < 2^28 (ATen uniform_int_from_to; larger ranges consume 64 bits per element and are left to torch). */
 int c3dgs_mt19937_fill(uint32_t* state, int64_t* left, int64_t* next, uint32_t* out, int64_t n);
 int c3dgs_draws_to_indices(int64_t n, int64_t range, const uint32_t* raw, int64_t* out, void* stream);
+/* device-side address of a page-locked host buffer, or NULL when it is not mapped for the device: c3dgs_draws_to_indices may then be
+ * given that address as `raw` and reads the words over the bus itself (no copy operation in the stream). */
+void* c3dgs_host_buffer_device_address(const void* host_ptr);
+/* the same fed from (pinned) host memory in one call: copies n raw words to raw_dev on the stream, then converts them. A rank of a
+ * sharded run uploads only ITS slice of the batch's draws (raw_host + lo, n = hi - lo). */
+int c3dgs_draws_upload(int64_t n, int64_t range, const uint32_t* raw_host, uint32_t* raw_dev, int64_t* out, void* stream);
 
 /* ---- L1 + SSIM loss (reference utils/loss_utils.py:17-63, used at finetune.py:48) ----
  * forward: sums[0..63] add up to sum |img - gt|, sums[64..127] to sum ssim_map (float64, device, zeroed by the callee;

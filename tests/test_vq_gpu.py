@@ -180,7 +180,7 @@ def test_batch_draws_on_device_equal_the_cpu_generator_stream(hip):
     torch.rand(3)
     d = _BatchDraws(N, chunk, steps, torch.device("cuda", 0))
     assert d.key is not None                             # the fast path is the one under test
-    got = [d.next_batch() for _ in range(steps)]
+    got = [d.next_batch().clone() for _ in range(steps)]       # the returned tensor is the loop's staging buffer: reused per call
     d.finish()
     for a, b in zip(ref, got):
         assert b.dtype == torch.int64 and torch.equal(a, b.cpu())
@@ -191,9 +191,16 @@ def test_batch_draws_on_device_equal_the_cpu_generator_stream(hip):
     after5 = torch.rand(4)
     torch.manual_seed(22)
     d = _BatchDraws(N, chunk, steps, torch.device("cuda", 0))
-    got5 = [d.next_batch() for _ in range(5)]
+    got5 = [d.next_batch().clone() for _ in range(5)]
     d.finish()
     assert all(torch.equal(a, b.cpu()) for a, b in zip(ref5, got5)) and torch.equal(torch.rand(4), after5)
+    # a rank's slice: the whole batch is drawn, only [lo, hi) is uploaded and converted
+    torch.manual_seed(22)
+    d = _BatchDraws(N, chunk, steps, torch.device("cuda", 0))
+    lo, hi = chunk // 8 * 3, chunk // 8 * 4 + 5
+    sl = [d.next_batch(lo, hi).clone() for _ in range(5)]
+    d.finish()
+    assert all(torch.equal(a[lo:hi], b.cpu()) for a, b in zip(ref5, sl)) and torch.equal(torch.rand(4), after5)
 
 
 def test_vq_features_default_draws_equal_explicit_batches(hip):

@@ -22,7 +22,7 @@ for r in csv.DictReader(open(f)):
     per = calls / steps
     tot += per
     print(f"{per:6.2f} launches/step  {float(r['AverageNs'])/1e3:8.1f} us avg  {r['Name'][:100]}")
-print(f"{tot:6.2f} kernel launches per Lloyd step in total (+ one host->device copy of the raw draws)")
+print(f"{tot:6.2f} kernel launches per Lloyd step in total (the raw draws are read from page-locked host memory by draws_to_indices_kernel: no copy)")
 PY
 done
 cat "$OUT"
