@@ -62,7 +62,11 @@ def _compile(name, extra, verbose):
 # that tests/test_sort_gpu.py::test_sort_timeout_is_not_silent exercises (loaded through C3DGS_LIB_PATH in a child process).
 # "lanes": the blend kernels count how many pixel lanes use each (wave, Gaussian) pair (tools/lane_efficiency.py).
 VARIANTS = {"spin1": {"radix_sort.hip": ["-DC3DGS_OS_SPIN_LIMIT=1u"]},
-            "lanes": {"render.hip": ["-DC3DGS_COUNT_LANES"]},
+            "lanes": {"render.hip": ["-DC3DGS_COUNT_LANES", "-fno-slp-vectorize"]},
+            # "bwdtime": render_backward sums the shader clock per phase (staging / list compaction / group loop / flush)
+            "bwdtime": {"render.hip": ["-DC3DGS_BWD_TIMING", "-fno-slp-vectorize"]},
+            # (timing-only ablations of render_backward, WRONG gradients, are built by hand: C3DGS_RENDER_FLAGS="-fno-slp-vectorize
+            #  -DC3DGS_BWD_ABLATE=1|2|3" python -m c3dgs_amd.build; bit 0 = no partial-sum stores, bit 1 = cache-resident record gathers)
             # "ostime": the digit passes of the onesweep sorts stamp the shader clock at their phase boundaries (tools/sort_phases.py)
             "ostime": {"radix_sort.hip": ["-DC3DGS_OS_TIMING"]}}
 

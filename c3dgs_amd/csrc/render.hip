@@ -34,6 +34,16 @@ constexpr int BATCH = 256;
 // The product build never touches them; c3dgs_debug_lane_counters() reads and clears them.
 __device__ unsigned long long g_lane_counters[16];
 
+#ifndef C3DGS_BWD_ABLATE
+#define C3DGS_BWD_ABLATE 0      // timing-only experiment builds: bit 0 = no partial-sum stores, bit 1 = cache-resident record gathers
+#endif
+#ifdef C3DGS_BWD_TIMING
+// phase clocks of render_backward (experiment build variant "bwdtime"): shader-clock ticks summed over all waves:
+// g_lane_counters[8 + {0: staging incl. its two barriers, 1: list compaction, 2: group loop, 3: flush incl. barrier, 4: prologue, 5: waves}]
+#define BT_STAMP(var) const unsigned long long var = __builtin_readcyclecounter();
+#else
+#define BT_STAMP(var)
+#endif
 #ifdef C3DGS_COUNT_LANES
 struct LaneCount {
     unsigned long long pairs = 0, slots = 0, lanes = 0, live = 0, half = 0, blk = 0, lists = 0, aux = 0;
@@ -456,6 +466,10 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     }
     // longest tiles first (tile_order: descending tile_used), so that the last workgroups to start are the short ones
     if ((int)blockIdx.x >= T) return;
+    BT_STAMP(bt_begin)
+#ifdef C3DGS_BWD_TIMING
+    unsigned long long bt_stage = 0, bt_list = 0, bt_loop = 0, bt_flush = 0, bt_s0 = 0, bt_s1 = 0, bt_s2 = 0, bt_s3 = 0, bt_f0 = 0;
+#endif
     const int tile = (int)tile_order[blockIdx.x];
     // staged entries as in the forward: 32-byte records {x, y, conic a, b | conic c, opacity, r, g}, blue and the instance's
     // backward slot in arrays of their own; the candidate lists hold record BYTE OFFSETS that feed the LDS reads directly
@@ -510,31 +524,62 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     LaneCount lc;
 #endif
 
+    uint32_t next_id = 0u, next_qm = 0u;
+    {
+        const int p0 = used - 1 - tid;
+        if (p0 >= 0) { next_id = point_list[range.x + p0]; next_qm = qmask[range.x + p0]; }
+    }
+    BT_STAMP(bt_pro)
     for (int r = 0; r < rounds; r++) {
+        BT_STAMP(bt0)
         __syncthreads();                                         // previous flush has read s_part / s_slot
+        BT_STAMP(btA)
         const int mypos = used - 1 - (r * BATCH + tid);          // back to front (backward.cu:466-479)
         uint32_t qm = 0u;
         if (mypos >= 0) {
-            const uint32_t id = point_list[range.x + mypos];
+            // the entry's Gaussian id and quadrant mask were requested one round ago (below): the record gather is the only
+            // memory round trip left in front of this round's blending (measured with the "bwdtime" variant: the dependent chain
+            // point list -> record was 31 % of a wave's lifetime, more than its group loop)
+#if C3DGS_BWD_ABLATE & 2
+            const uint32_t id = next_id & 4095u;                  // timing-only build: records from a cache-resident corner of the array
+#else
+            const uint32_t id = next_id;
+#endif
+            qm = next_qm;
             float4 a = splat[3 * (size_t)id], b = splat[3 * (size_t)id + 1];
             const float4 c = splat[3 * (size_t)id + 2];
             prescale_conic(a, b);
             const uint32_t off = __float_as_uint(c.y), lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
             const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
+#if C3DGS_BWD_ABLATE & 2
+            s_slot[tid] = range.x + (uint32_t)mypos;              // timing-only build: a slot that exists (the record is not this entry's)
+            (void)off; (void)x0; (void)y0; (void)x1;
+#else
             s_slot[tid] = block_base[id >> 8] + off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+#endif
             s_ab[tid][0] = a; s_ab[tid][1] = b; s_c[tid] = c.x;
-            qm = qmask[range.x + mypos];                          // written by the forward for every entry it staged
+        }
+        {   // next round's ids / masks: in flight behind this round's blending (two registers)
+            const int npos = mypos - BATCH;
+            if (npos >= 0) { next_id = point_list[range.x + npos]; next_qm = qmask[range.x + npos]; }   // qmask: written by the forward for every entry it staged
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const unsigned long long bm = __ballot((qm >> q) & 1u);
             if (lane == 0) s_mask[q][wave] = bm;
         }
+        BT_STAMP(btB)
 #pragma unroll
         for (int w = 0; w < 2; w++)
 #pragma unroll
             for (int q = 0; q < NPART; q++) s_part[w][tid][q] = 0.f;
+        BT_STAMP(btC)
         __syncthreads();
+        BT_STAMP(bt1)
+#ifdef C3DGS_BWD_TIMING
+        bt_stage += bt1 - bt0;
+        bt_s0 += btA - bt0; bt_s1 += btB - btA; bt_s2 += btC - btB; bt_s3 += bt1 - btC;
+#endif
 
         const int cnt = min(BATCH, used - r * BATCH);
         const int pos0 = used - 1 - r * BATCH;                   // position of batch entry j is pos0 - j
@@ -546,6 +591,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
         // bench scene -- adds zeros; testing for it per Gaussian cost more than it saved.)
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
+        BT_STAMP(bt2)
         int nw = 0;
         {
             const unsigned long long lt = (1ull << lane) - 1ull;
@@ -564,6 +610,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        BT_STAMP(bt3)
         for (int k = 0; k < nw; k += GROUP_G) {
             const uint32_t* lrow = &s_list[wave][k];
             const uint4 row0 = *reinterpret_cast<const uint4*>(lrow);
@@ -623,8 +670,17 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the list is rebuilt for the second half
         __builtin_amdgcn_wave_barrier();
+        BT_STAMP(bt4)
+#ifdef C3DGS_BWD_TIMING
+        bt_list += bt3 - bt2; bt_loop += bt4 - bt3;
+#endif
         }
+        BT_STAMP(bt5)
         __syncthreads();
+        BT_STAMP(bt5b)
+#ifdef C3DGS_BWD_TIMING
+        bt_f0 += bt5b - bt5;
+#endif
         if (tid < cnt) {
             const uint32_t slot = s_slot[tid];
             float* dst = partials + (size_t)slot * NPART;
@@ -632,14 +688,33 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
 #pragma unroll
             for (int q = 0; q < NPART; q++) t[q] = s_part[0][tid][q] + s_part[1][tid][q];   // (w0 + w1) + (w2 + w3): fixed order
             // network order {c0, c1, c2, S0, Sx, Sxx, Sy, Sxy, Syy} -> what backward_preprocess.hip expects
+            // (writing a slot cooperatively -- consecutive lanes on consecutive floats, 7 slots per store instruction -- measured
+            // SLOWER: the flush went from 13 % to 19 % of a wave's lifetime, "bwdtime" variant)
+#if !(C3DGS_BWD_ABLATE & 1)
             dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2];
             dst[3] = t[3]; dst[4] = t[4]; dst[5] = t[6];
             dst[6] = t[5]; dst[7] = t[7]; dst[8] = t[8];
+#else
+            if (t[0] == 123.456f) dst[0] = t[1] + t[2] + t[3] + t[4] + t[5] + t[6] + t[7] + t[8];     // timing-only build: no slot stores
+#endif
             touched[slot] = 1;
         }
+        BT_STAMP(bt6)
+#ifdef C3DGS_BWD_TIMING
+        bt_flush += bt6 - bt5;
+#endif
     }
 #ifdef C3DGS_COUNT_LANES
     lc.flush(8, lane);
+#endif
+#ifdef C3DGS_BWD_TIMING
+    if (lane == 0) {
+        atomicAdd(&g_lane_counters[8], bt_stage); atomicAdd(&g_lane_counters[9], bt_list); atomicAdd(&g_lane_counters[10], bt_loop);
+        atomicAdd(&g_lane_counters[11], bt_flush); atomicAdd(&g_lane_counters[12], bt_pro - bt_begin); atomicAdd(&g_lane_counters[13], 1ull);
+        atomicAdd(&g_lane_counters[14], (unsigned long long)__builtin_readcyclecounter() - bt_begin);
+        atomicAdd(&g_lane_counters[0], bt_s0); atomicAdd(&g_lane_counters[1], bt_s1); atomicAdd(&g_lane_counters[2], bt_s2);
+        atomicAdd(&g_lane_counters[3], bt_s3); atomicAdd(&g_lane_counters[4], bt_f0);
+    }
 #endif
 }
 
