@@ -833,7 +833,7 @@ def bench_vq(c3dgs_amd, _lib, dev, rank, world, steps, cpu_baseline):
     # 2^15 / 2^16-point slice of it is assigned + accumulated, the update runs -- the fixed per-step part that bounds strong scaling
     if world == 1:
         try:
-            out["slice_step_ms"] = {str(n): vq_slice_step(vqm, feats, imp, K, B, n, max(steps, 30), dev) for n in (2 ** 15, 2 ** 16, 2 ** 18)}
+            out["slice_step_ms"] = {str(n): vq_slice_step(vqm, feats, imp, K, B, n, max(steps, 100), dev) for n in (2 ** 15, 2 ** 16, 2 ** 18)}
             out["slice_step_ms"]["what"] = ("ms per full Lloyd step (batch draw -> update, no collective) when only the first n points of each "
                                             "2^18-point batch are this rank's: n = 2^15 / 2^16 = one of 8 / 4 ranks; launches per step: "
                                             "draws_to_indices, search, exact re-scan, accumulate (+ distance sum), update (+ next split, clears) "

@@ -87,9 +87,9 @@ def _exactness_properties(hip, x, cb, d, i, g, probes=64, rows=4096):
 
 
 def test_vq_covariance_batch_full_size(hip, orc):
-    """configs[3] covariance codebook: batch 2^20 x K=2048 x D=6 (the LDS-accumulate shape). The first 2^15 points are
-    checked bit-exactly against the oracle, all of them through the exactness properties, and one Lloyd step's sums against
-    float64 index_add of the same assignment."""
+    """configs[3] covariance codebook: batch 2^20 x K=2048 x D=6 (the LDS-accumulate shape). 2^15 points spread over the whole
+    batch (stride 32) are checked bit-exactly against the oracle, all of them through the exactness properties, and one Lloyd
+    step's sums against float64 index_add of the same assignment."""
     g = torch.Generator().manual_seed(8)
     B, K, D = 2 ** 20, 2048, 6
     x = (torch.randn(B, D, generator=g) * 0.1).float()
@@ -98,10 +98,10 @@ def test_vq_covariance_batch_full_size(hip, orc):
     w = torch.rand(B, generator=g).pow(4).float()
     xd, cbd, wd = x.cuda(), cb.cuda(), w.cuda()
     d, i = hip.weightedDistance(xd, cbd)
-    n = 2 ** 15
-    d_ref, i_ref = orc.weighted_distance(x[:n].numpy(), cb.numpy())
-    np.testing.assert_array_equal(i[:n].cpu().numpy(), i_ref)
-    np.testing.assert_array_equal(d[:n].cpu().numpy().view(np.uint32), d_ref.view(np.uint32))
+    sel = torch.arange(0, B, B // 2 ** 15)[:2 ** 15]              # a strided sample over the whole batch, not its first points
+    d_ref, i_ref = orc.weighted_distance(x[sel].numpy(), cb.numpy())
+    np.testing.assert_array_equal(i[sel.cuda()].cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(d[sel.cuda()].cpu().numpy().view(np.uint32), d_ref.view(np.uint32))
     _exactness_properties(hip, xd, cbd, d, i, g)
     vqm = hip.VectorQuantize(D, K, decay=0.8).cuda()
     vqm.codebook.data = cbd.clone()
