@@ -289,6 +289,8 @@ render_forward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ran
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         uint32_t last_off = NO_ENTRY;                    // record offset of the last Gaussian this pixel blended in this batch
+        // (Requesting record g + 1 before Gaussian g is blended, as render_backward does, measured the same here, 0.265-0.274 ms, and
+        // requesting the next row's list words and first record ahead measured slower, 0.288 ms; the compiler's own placement stays.)
         for (int k = 0; k < nw; k += 8) {
             // the wave's early-out is tested once per row of 8, not per Gaussian: finished pixels blend nothing either
             // way, and a per-Gaussian test (ballot + scalar branch) costs more than the work it saves
@@ -415,12 +417,11 @@ __device__ __forceinline__ void transpose_reduce_step(float* v, bool hi)
                    "v"(b[base + half + 1]), "v"(b[base + half + 2]), "v"(b[base + half + 3]))
 
 // column levels: v[48] = 8 Gaussians x 6 values -> u[0..5] = the sums over the lane's 8-pixel row of the 6 values of
-// Gaussian slot beta(lane) = 4 * bit2 + 2 * bit0 + bit1
-__device__ __forceinline__ void reduce_columns_48(const float* v, float* u, int lane)
+// Gaussian slot beta(lane) = 4 * bit2 + 2 * bit0 + bit1.
+// 48 -> 24 (in the group loop, interleaved with the Gaussians' bodies): row_half_mirror (i <-> 7 - i); lanes with bit 2 clear =
+// banks 0,2 keep v[k], banks 1,3 keep v[k+24]. 24 -> 12 -> 6 here.
+__device__ __forceinline__ void reduce_columns_24(float* u, int lane)
 {
-    // 48 -> 24: row_half_mirror (i <-> 7 - i); lanes with bit 2 clear = banks 0,2 keep v[k], banks 1,3 keep v[k+24]
-#pragma unroll
-    for (int q = 0; q < 24; q += 4) C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, q, 24);
     transpose_reduce_step<24, 0xB1>(u, (lane & 1) != 0);   // quad_perm [1,0,3,2]: partners share a bank -> selects
     transpose_reduce_step<12, 0x4E>(u, (lane & 2) != 0);   // quad_perm [2,3,0,1]
 }
@@ -500,6 +501,8 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
     if (used <= 0) return;
     const int rounds = (used + BATCH - 1) / BATCH;
     if (tid == 0) { s_ab[BATCH][0] = make_float4(0, 0, 0, 0); s_ab[BATCH][1] = make_float4(0, 0, 0, 0); s_c[BATCH] = 0.f; }
+    // every list word starts as the sentinel's offset: the group loop requests the row BEHIND its last group ahead of time
+    for (int q = tid; q < 4 * (BATCH / 2 + GROUP_G); q += 256) (&s_list[0][0])[q] = (uint32_t)BATCH * REC_BYTES;
 
     const float T_final = inside ? final_Ts[pix] : 0.f;         // backward.cu:441-447
     float Tr = T_final;
@@ -611,17 +614,33 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         BT_STAMP(bt3)
+        // Software pipeline, two levels: inside a group, record g + 1 is requested from LDS before Gaussian g is blended; across
+        // groups, the NEXT group's list row and first record are requested behind this group's reduction (the list is padded, so
+        // the row behind the last group exists; it is not used). Left to the compiler, a group started with two dependent LDS
+        // round trips (row, then record) and every further record read sat directly in front of its first use.
+        uint4 row0 = *reinterpret_cast<const uint4*>(&s_list[wave][0]);
+        uint4 row1 = *reinterpret_cast<const uint4*>(&s_list[wave][4]);
+        float4 a_n = *reinterpret_cast<const float4*>(rec_base + row0.x);
+        float4 b_n = *reinterpret_cast<const float4*>(rec_base + row0.x + 16);
+        float c_n = *reinterpret_cast<const float*>(blue_base + (row0.x >> 3));
         for (int k = 0; k < nw; k += GROUP_G) {
             const uint32_t* lrow = &s_list[wave][k];
-            const uint4 row0 = *reinterpret_cast<const uint4*>(lrow);
-            const uint4 row1 = *reinterpret_cast<const uint4*>(lrow + 4);
             const uint32_t e[GROUP_G] = { row0.x, row0.y, row0.z, row0.w, row1.x, row1.y, row1.z, row1.w };
             float v[GROUP_G * NCOL];
+            float u[GROUP_G * NCOL / 2];
+            // batch entry of this lane's Gaussian slot (the list's padding entries are the sentinel, BATCH): requested here, used by
+            // the row levels behind the loop (there it was an exposed chain of two LDS round trips)
+            const uint32_t my_off = lrow[beta];
 #pragma unroll
             for (int g = 0; g < GROUP_G; g++) {
-                const float4 a = *reinterpret_cast<const float4*>(rec_base + e[g]);
-                const float4 b = *reinterpret_cast<const float4*>(rec_base + e[g] + 16);
-                const float cblue = *reinterpret_cast<const float*>(blue_base + (e[g] >> 3));
+                const float4 a = a_n, b = b_n;
+                const float cblue = c_n;
+                if (g + 1 < GROUP_G) {
+                    a_n = *reinterpret_cast<const float4*>(rec_base + e[g + 1]);
+                    b_n = *reinterpret_cast<const float4*>(rec_base + e[g + 1] + 16);
+                    c_n = *reinterpret_cast<const float*>(blue_base + (e[g + 1] >> 3));
+                }
+                __builtin_amdgcn_sched_barrier(0);               // keep the reads above in front of this Gaussian's arithmetic
                 float dx, dy, G, alpha;
                 bool hit = gaussian_alpha(a.x, a.y, a.z, a.w, b.x, b.y, pxf, pyf, dx, dy, G, alpha);
                 hit = hit && ((int)e[g] > thr);                  // backward.cu:486-488
@@ -646,12 +665,24 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                 v[g * NCOL + 3] = w;
                 v[g * NCOL + 4] = wx;
                 v[g * NCOL + 5] = wx * dx;
+                // First column level (48 -> 24: value q pairs with value q + 24, i.e. Gaussian g with Gaussian g + 4) as soon as
+                // both operands exist, four outputs at a time: the group then holds at most 24 + 6 live values instead of 48,
+                // which leaves the register allocator room (96 registers = five waves per SIMD) to request the NEXT Gaussian's
+                // record from LDS while this one is blended; with all 48 live every record read sat directly in front of its
+                // first use (three LDS latencies per Gaussian and wave, exposed).
+                if (g == 4) { C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, 0, 24); }
+                if (g == 5) { C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, 4, 24); C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, 8, 24); }
+                if (g == 6) { C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, 12, 24); }
+                if (g == 7) { C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, 16, 24); C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, 20, 24); }
             }
-            float u[GROUP_G * NCOL / 2];
-            reduce_columns_48(v, u, lane);
+            row0 = *reinterpret_cast<const uint4*>(lrow + GROUP_G);          // next group's row (in bounds: the list is padded)
+            row1 = *reinterpret_cast<const uint4*>(lrow + GROUP_G + 4);
+            reduce_columns_24(u, lane);
+            a_n = *reinterpret_cast<const float4*>(rec_base + row0.x);          // ... and its first record, behind the row levels
+            b_n = *reinterpret_cast<const float4*>(rec_base + row0.x + 16);
+            c_n = *reinterpret_cast<const float*>(blue_base + (row0.x >> 3));
             // batch entry of this lane's Gaussian slot (the list's padding entries are the sentinel, BATCH) and this pixel
             // row's dy to that Gaussian: the same subtraction gaussian_alpha made for it
-            const uint32_t my_off = lrow[beta];
             const int myj = (int)(my_off >> 5);                  // offset / 32
             const float dyb = *reinterpret_cast<const float*>(rec_base + my_off + 4) - pyf;
             // row sums {c0, c1, c2, S0, Sx, Sxx} of Gaussian slot beta -> the nine terms {.., Sy, Sxy | Syy}
