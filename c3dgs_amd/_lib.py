@@ -50,7 +50,7 @@ class StageTime(C.Structure):
 
 
 class ImageLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("total_bytes", "final_T", "n_contrib", "ranges", "tile_used")]
+    _fields_ = [(n, C.c_size_t) for n in ("total_bytes", "final_T", "n_contrib", "ranges", "tile_used", "tile_order")]
 
 
 class QatParams(C.Structure):

@@ -30,12 +30,16 @@ size_t scan_temp_bytes(int P)
     return m < 256 ? 256 : m;
 }
 
-size_t sort_temp_bytes(int R, int end_bit)
+size_t sort_temp_bytes(int R, int end_bit, int key_bytes)
 {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint16_t*)nullptr, (uint16_t*)nullptr,
-                                    (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)R, 0u, (unsigned)end_bit);
-    const size_t os = onesweep_tile_temp_bytes(R, end_bit);
+    if (key_bytes == 4)
+        (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)R, 0u, (unsigned)end_bit);
+    else
+        (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint16_t*)nullptr, (uint16_t*)nullptr,
+                                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)R, 0u, (unsigned)end_bit);
+    const size_t os = onesweep_tile_temp_bytes(R, end_bit, key_bytes);
     if (os > bytes) bytes = os;
     // after the sort the region is reused for the R quadrant-mask bytes
     const size_t reuse = align_up((size_t)(R > 0 ? R : 1));
@@ -67,11 +71,17 @@ hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, ui
     return hipGetLastError();
 }
 
-hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin,
+hipError_t run_tile_sort(void* temp, size_t temp_bytes, const void* kin, void* kout, int key_bytes, const uint32_t* vin,
                          uint32_t* vout, int R, int end_bit, hipStream_t s)
 {
-    if (onesweep_enabled() && (size_t)R < ((size_t)1 << 30)) return onesweep_tile_sort(temp, temp_bytes, kin, kout, vin, vout, R, end_bit, s);
-    return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)R, 0u, (unsigned)end_bit, s);
+    if (key_bytes == 4) {       // more than 65,536 tiles: 32-bit tile keys, three digit passes for 17-24 tile bits
+        if (onesweep_enabled() && (size_t)R < ((size_t)1 << 30))
+            return onesweep_tile_sort32(temp, temp_bytes, (const uint32_t*)kin, (uint32_t*)kout, vin, vout, R, end_bit, s);
+        return rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t*)kin, (uint32_t*)kout, vin, vout, (size_t)R, 0u, (unsigned)end_bit, s);
+    }
+    if (onesweep_enabled() && (size_t)R < ((size_t)1 << 30))
+        return onesweep_tile_sort(temp, temp_bytes, (const uint16_t*)kin, (uint16_t*)kout, vin, vout, R, end_bit, s);
+    return rocprim::radix_sort_pairs(temp, temp_bytes, (const uint16_t*)kin, (uint16_t*)kout, vin, vout, (size_t)R, 0u, (unsigned)end_bit, s);
 }
 
 } // namespace c3dgs

@@ -93,8 +93,11 @@ static int validate(const c3dgs_raster_params* p, bool indexed, bool is_backward
         return fail(C3DGS_E_INVALID, "non-indexed rasterizer: sh_indices / g_indices / scale_factors must be NULL");
     }
     if (tiles_x(p->W) > 65535 || tiles_y(p->H) > 65535) return fail(C3DGS_E_INVALID, "image too large for 16-bit tile coordinates");
-    if ((long long)tiles_x(p->W) * tiles_y(p->H) > 65536)       // tile ids are 16-bit sort keys (up to 4096 x 4096 pixels)
-        return fail(C3DGS_E_INVALID, "image has more than 65536 tiles (16-bit tile keys): at most 16.7 Mpixel");
+    // Up to 65,536 tiles the tile keys are 16 bits, above 32 bits (common.hpp: tile_key_bytes). The bound that remains: the pair
+    // emission divides an instance's number inside its rectangle by the rectangle's width with a multiply-high that is exact
+    // while (tiles per row)^2 x (tile rows) < 2^32 -- e.g. 16384 x 16384 pixels = 2^30, 7680 x 4320 = 6.2e7.
+    if ((unsigned long long)tiles_x(p->W) * tiles_x(p->W) * tiles_y(p->H) >= (1ull << 32))
+        return fail(C3DGS_E_INVALID, "image too large: (tiles per row)^2 x (tile rows) must stay below 2^32");
     return C3DGS_OK;
 }
 
@@ -182,11 +185,11 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
         C3DGS_STAGE("duplicate_with_keys", p.debug, s);
         const int end_bit = (int)higher_msb((uint32_t)T);                           // tile bits only (rasterizer_impl.cu:298)
         { StageTimer t_(ST_SORT, s);
-          C3DGS_HIP_TRY(run_tile_sort(b.sort_temp, b.sort_temp_bytes, b.keys_unsorted, b.keys_sorted, b.values_unsorted,
+          C3DGS_HIP_TRY(run_tile_sort(b.sort_temp, b.sort_temp_bytes, b.keys_unsorted, b.keys_sorted, b.key_bytes, b.values_unsorted,
                                       b.point_list, R, end_bit, s)); }               // K6, binning stage 2
         C3DGS_STAGE("sort", p.debug, s);
         if (p.debug && onesweep_timed_out(s)) return fail(C3DGS_E_HIP, "tile sort: look-back timed out");
-        { StageTimer t_(ST_RANGES, s); launch_identify_ranges(R, b.keys_sorted, img.ranges, sort_err, s); } // K8
+        { StageTimer t_(ST_RANGES, s); launch_identify_ranges(R, b.keys_sorted, b.key_bytes, img.ranges, sort_err, s); } // K8
         C3DGS_STAGE("identify_ranges", p.debug, s);
     }
     { StageTimer t_(ST_RENDER_FWD, s);
@@ -247,8 +250,8 @@ static int backward_impl(const c3dgs_raster_params* pp, bool indexed, const int3
     // Workspace: partial sums | flags | tile schedule | per-workgroup lists of the blended Gaussians (id, slot) and their lengths
     const size_t r1 = (size_t)(R > 0 ? R : 1), p256 = ((size_t)P + 1023) / 1024 * 1024;   // whole lists (<= 1024 entries each)
     uint8_t* touched = (uint8_t*)partials + align_up(r1 * PARTIAL_FLOATS * sizeof(float));
-    uint32_t* tile_order = (uint32_t*)(touched + align_up(r1));
-    uint32_t* live_ids = tile_order + 65536;
+    uint32_t* tile_order = img.tile_order;                     // T words of the image buffer (scratch of this call)
+    uint32_t* live_ids = (uint32_t*)(touched + align_up(r1)) + 65536;   // (the 256 KB in front are the pre-version-4 home of the tile schedule)
     uint32_t* live_slots = live_ids + p256;
     uint32_t* live_count = live_slots + p256;
     // one launch: tile schedule of the blend kernel + the flag clear. The codebook-gradient clear (80 MB on the bench view, needed

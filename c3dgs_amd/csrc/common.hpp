@@ -41,7 +41,7 @@ inline int fail(int code, const std::string& msg) { set_error(msg); return code;
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 size_t scan_temp_bytes(int P);      // max(scan, depth sort) temporary storage for P Gaussians
-size_t sort_temp_bytes(int R, int end_bit);
+size_t sort_temp_bytes(int R, int end_bit, int key_bytes = 2);
 
 inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
 inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
@@ -82,15 +82,21 @@ inline void geom_layout(int P, c3dgs_geom_layout* L)
 // the same data arrives with two 16-byte loads from one line per Gaussian (preprocess 0.268 -> see DESIGN.md).
 inline size_t geom_gtab_bytes(const c3dgs_raster_params& p) { return (p.g_indices && p.scales) ? align_up((size_t)(p.GS > 0 ? p.GS : 1) * 32) : 0; }
 
+// Tile keys are 16-bit up to 65,536 tiles (4096 x 4096 pixels) and 32-bit above (e.g. 7680 x 4320 = 129,600 tiles): the
+// reference's 64-bit keys (rasterizer_impl.cu:98-108) have no tile limit, and neither has this path; the common case keeps
+// its 6-byte instances and two digit passes.
+inline int tile_key_bytes(int W, int H) { return (long long)tiles_x(W) * tiles_y(H) > 65536 ? 4 : 2; }
+
 inline void binning_layout(int R, int W, int H, c3dgs_binning_layout* L)
 {
     size_t o = 0, r = (size_t)(R > 0 ? R : 1);
     int end_bit = (int)higher_msb((uint32_t)(tiles_x(W) * tiles_y(H)));
-    L->keys_unsorted = o;   o = align_up(o + r * 2);
+    const size_t kb = (size_t)tile_key_bytes(W, H);
+    L->keys_unsorted = o;   o = align_up(o + r * kb);
     L->values_unsorted = o; o = align_up(o + r * 4);
-    L->keys_sorted = o;     o = align_up(o + r * 2);
+    L->keys_sorted = o;     o = align_up(o + r * kb);
     L->point_list = o;      o = align_up(o + r * 4);
-    L->sort_temp = o;       L->sort_temp_bytes = sort_temp_bytes((int)r, end_bit);
+    L->sort_temp = o;       L->sort_temp_bytes = sort_temp_bytes((int)r, end_bit, (int)kb);
     o = align_up(o + L->sort_temp_bytes);
     L->total_bytes = o;
 }
@@ -102,6 +108,7 @@ inline void image_layout(int W, int H, c3dgs_image_layout* L)
     L->n_contrib = o; o = align_up(o + n * 4);
     L->ranges = o;    o = align_up(o + t * 8);
     L->tile_used = o; o = align_up(o + t * 4);
+    L->tile_order = o; o = align_up(o + t * 4);
     L->total_bytes = o;
 }
 
@@ -113,10 +120,10 @@ struct GeomPtrs {
     float4* gtab;     // indexed variant: the scale / rotation codebooks packed as one 32-byte row per entry (behind the P-sized part)
 };
 struct BinPtrs {
-    uint16_t* keys_unsorted; uint32_t* values_unsorted; uint16_t* keys_sorted; uint32_t* point_list;
-    void* sort_temp; size_t sort_temp_bytes;
+    void* keys_unsorted; uint32_t* values_unsorted; void* keys_sorted; uint32_t* point_list;   // keys: u16, or u32 above 65,536 tiles
+    void* sort_temp; size_t sort_temp_bytes; int key_bytes;
 };
-struct ImgPtrs { float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_used; };
+struct ImgPtrs { float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_used; uint32_t* tile_order; };
 
 inline GeomPtrs geom_ptrs(void* base, int P)
 {
@@ -131,14 +138,15 @@ inline BinPtrs bin_ptrs(void* base, int R, int W, int H)
 {
     c3dgs_binning_layout L; binning_layout(R, W, H, &L);
     char* b = (char*)base;
-    return { (uint16_t*)(b + L.keys_unsorted), (uint32_t*)(b + L.values_unsorted), (uint16_t*)(b + L.keys_sorted),
-             (uint32_t*)(b + L.point_list), (void*)(b + L.sort_temp), L.sort_temp_bytes };
+    return { (void*)(b + L.keys_unsorted), (uint32_t*)(b + L.values_unsorted), (void*)(b + L.keys_sorted),
+             (uint32_t*)(b + L.point_list), (void*)(b + L.sort_temp), L.sort_temp_bytes, tile_key_bytes(W, H) };
 }
 inline ImgPtrs img_ptrs(void* base, int W, int H)
 {
     c3dgs_image_layout L; image_layout(W, H, &L);
     char* b = (char*)base;
-    return { (float*)(b + L.final_T), (uint32_t*)(b + L.n_contrib), (uint2*)(b + L.ranges), (uint32_t*)(b + L.tile_used) };
+    return { (float*)(b + L.final_T), (uint32_t*)(b + L.n_contrib), (uint2*)(b + L.ranges), (uint32_t*)(b + L.tile_used),
+             (uint32_t*)(b + L.tile_order) };
 }
 
 // preprocess.hip
@@ -148,20 +156,22 @@ void launch_pack_codebook(const c3dgs_raster_params& p, float4* gtab, hipStream_
 void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, const uint32_t* sort_err, hipStream_t s);
 void launch_depth_order_scan(int P, const GeomPtrs& g, hipStream_t s);   // block totals of tiles_sorted -> depth_base[]
 void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, const uint32_t* sort_err, hipStream_t s);
-void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, const uint32_t* sort_err, hipStream_t s);
+void launch_identify_ranges(int R, const void* keys_sorted, int key_bytes, uint2* ranges, const uint32_t* sort_err, hipStream_t s);
 // binning.hip
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
                           uint32_t* vout, int P, const uint2* rects, uint2* rects_sorted, hipStream_t s);
-hipError_t run_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin,
+hipError_t run_tile_sort(void* temp, size_t temp_bytes, const void* kin, void* kout, int key_bytes, const uint32_t* vin,
                          uint32_t* vout, int R, int end_bit, hipStream_t s);
 // radix_sort.hip (hand-written onesweep; C3DGS_SORT_ROCPRIM=1 selects the rocPRIM path of binning.hip instead)
 bool onesweep_enabled();
 int onesweep_timed_out(hipStream_t s);   // debug mode only (synchronises): reads + clears the sticky error word
 uint32_t* onesweep_error_word();          // device address of the sticky look-back time-out word (0 = fine)
 size_t onesweep_depth_temp_bytes(int P);
-size_t onesweep_tile_temp_bytes(int R, int end_bit);
+size_t onesweep_tile_temp_bytes(int R, int end_bit, int key_bytes = 2);
 hipError_t onesweep_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
                                int P, const uint2* gather_src, uint2* gather_dst, hipStream_t s);
+hipError_t onesweep_tile_sort32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                                int R, int end_bit, hipStream_t s);   // 32-bit tile keys (more than 65,536 tiles)
 hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin, uint32_t* vout,
                               int R, int end_bit, hipStream_t s);
 // render.hip

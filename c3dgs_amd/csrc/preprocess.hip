@@ -400,9 +400,10 @@ block_totals_kernel(int n, const uint2* __restrict__ rects_sorted, uint32_t* __r
     if (threadIdx.x == 0) totals[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
+template <class K>   // tile key type: uint16_t, or uint32_t above 65,536 tiles
 __global__ void __launch_bounds__(256)
 duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint2* __restrict__ rects_sorted,
-                           const uint32_t* __restrict__ depth_base, uint16_t* __restrict__ keys, uint32_t* __restrict__ values,
+                           const uint32_t* __restrict__ depth_base, K* __restrict__ keys, uint32_t* __restrict__ values,
                            int grid_x, const uint32_t* __restrict__ sort_err)
 {
     // a depth sort whose look-back gave up (radix_sort.hip) left positions of `order` / `rects_sorted` unwritten: their stale
@@ -466,7 +467,7 @@ duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint
         for (int w = 0; w < wave; w++) before = max(before, s_wmax[w]);
         carry = max(max(carry, max(s_wmax[0], s_wmax[1])), max(s_wmax[2], s_wmax[3]));
         const uint32_t o0 = c0 + 4u * t;
-        uint16_t kq[4];
+        K kq[4];
         uint32_t vq[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -480,14 +481,17 @@ duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint
                 const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
                 const uint32_t local = o - first, w = (uint32_t)(x1 - x0), inv = s_inv[g];
                 // local / w as a multiply-high by ceil(2^32 / w): exact while local * w < 2^32, and local < rectangle area <=
-                // number of tiles <= 2^16 (tile keys are 16 bits), w < 2^16
+                // number of tiles (<= 2^16 with 16-bit tile keys; the C ABI admits at most 2^22 tiles), w <= 2^10 of them per row
                 const uint32_t ry = inv ? __umulhi(local, inv) : local, rx = local - ry * w;   // emission order: y outer, x inner (:98-108)
-                kq[e] = (uint16_t)((y0 + ry) * grid_x + (x0 + rx));
+                kq[e] = (K)((y0 + ry) * grid_x + (x0 + rx));
                 vq[e] = s_id[g];
             }
         }
         if (o0 >= out_begin && o0 + 4 <= out_end) {
-            *reinterpret_cast<uint2*>(keys + o0) = make_uint2((uint32_t)kq[0] | ((uint32_t)kq[1] << 16), (uint32_t)kq[2] | ((uint32_t)kq[3] << 16));
+            if constexpr (sizeof(K) == 2)
+                *reinterpret_cast<uint2*>(keys + o0) = make_uint2((uint32_t)kq[0] | ((uint32_t)kq[1] << 16), (uint32_t)kq[2] | ((uint32_t)kq[3] << 16));
+            else
+                *reinterpret_cast<uint4*>(keys + o0) = make_uint4((uint32_t)kq[0], (uint32_t)kq[1], (uint32_t)kq[2], (uint32_t)kq[3]);
             *reinterpret_cast<uint4*>(values + o0) = make_uint4(vq[0], vq[1], vq[2], vq[3]);
         } else {
 #pragma unroll
@@ -510,30 +514,43 @@ void launch_depth_order_scan(int P, const GeomPtrs& g, hipStream_t s)
 void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, const uint32_t* sort_err, hipStream_t s)
 {
     if (P <= 0) return;
-    duplicate_with_keys_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, g.depth_order, g.sorted_offsets, g.depth_base, b.keys_unsorted,
-                                                               b.values_unsorted, grid_x, sort_err);
+    if (b.key_bytes == 4)
+        duplicate_with_keys_kernel<uint32_t><<<(P + 255) / 256, 256, 0, s>>>(P, g.depth_order, g.sorted_offsets, g.depth_base,
+                                                                             (uint32_t*)b.keys_unsorted, b.values_unsorted, grid_x, sort_err);
+    else
+        duplicate_with_keys_kernel<uint16_t><<<(P + 255) / 256, 256, 0, s>>>(P, g.depth_order, g.sorted_offsets, g.depth_base,
+                                                                             (uint16_t*)b.keys_unsorted, b.values_unsorted, grid_x, sort_err);
 }
 
 // ---- K8: reference rasterizer_impl.cu:116-138 (ranges pre-zeroed by the caller, :308)
+template <class K>
 __global__ void __launch_bounds__(256)
-identify_ranges_kernel(int L, const uint16_t* __restrict__ keys, uint2* __restrict__ ranges, const uint32_t* __restrict__ sort_err)
+identify_ranges_kernel(int L, const K* __restrict__ keys, uint2* __restrict__ ranges, const uint32_t* __restrict__ sort_err)
 {
     // after a sort time-out the "sorted" keys are stale memory: used as tile numbers they would index past `ranges`. The ranges
     // stay all-zero instead, so render_forward walks no list at all (and returns its NaN image)
     if (*sort_err) return;
-    // eight sorted keys per thread (one 16-byte load + the key in front of them): the buffer is 256-byte aligned and
-    // padded, so the last thread's load stays inside it
+    // eight sorted keys per thread (16-byte loads + the key in front of them): the buffer is 256-byte aligned and
+    // padded, so the last thread's loads stay inside it
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int i0 = j * 8;
     if (i0 >= L) return;
-    const uint4 v = reinterpret_cast<const uint4*>(keys)[j];
-    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+    uint32_t cur8[8];
+    if constexpr (sizeof(K) == 2) {
+        const uint4 v = reinterpret_cast<const uint4*>(keys)[j];
+        const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int e = 0; e < 8; e++) cur8[e] = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+    } else {
+        const uint4 v0 = reinterpret_cast<const uint4*>(keys)[2 * j], v1 = reinterpret_cast<const uint4*>(keys)[2 * j + 1];
+        cur8[0] = v0.x; cur8[1] = v0.y; cur8[2] = v0.z; cur8[3] = v0.w; cur8[4] = v1.x; cur8[5] = v1.y; cur8[6] = v1.z; cur8[7] = v1.w;
+    }
     uint32_t prev = i0 > 0 ? (uint32_t)keys[i0 - 1] : 0xffffffffu;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const int idx = i0 + e;
         if (idx < L) {
-            const uint32_t cur = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+            const uint32_t cur = cur8[e];
             if (cur != prev) {
                 if (idx > 0) ranges[prev].y = (uint32_t)idx;
                 ranges[cur].x = (uint32_t)idx;
@@ -544,11 +561,12 @@ identify_ranges_kernel(int L, const uint16_t* __restrict__ keys, uint2* __restri
     }
 }
 
-void launch_identify_ranges(int R, const uint16_t* keys_sorted, uint2* ranges, const uint32_t* sort_err, hipStream_t s)
+void launch_identify_ranges(int R, const void* keys_sorted, int key_bytes, uint2* ranges, const uint32_t* sort_err, hipStream_t s)
 {
     if (R <= 0) return;
     const int threads = (R + 7) / 8;
-    identify_ranges_kernel<<<(threads + 255) / 256, 256, 0, s>>>(R, keys_sorted, ranges, sort_err);
+    if (key_bytes == 4) identify_ranges_kernel<uint32_t><<<(threads + 255) / 256, 256, 0, s>>>(R, (const uint32_t*)keys_sorted, ranges, sort_err);
+    else identify_ranges_kernel<uint16_t><<<(threads + 255) / 256, 256, 0, s>>>(R, (const uint16_t*)keys_sorted, ranges, sort_err);
 }
 
 } // namespace c3dgs

@@ -470,7 +470,15 @@ bool onesweep_enabled()
     return on;
 }
 size_t onesweep_depth_temp_bytes(int P) { return os_temp_bytes<uint32_t>((size_t)(P > 0 ? P : 1), 32); }
-size_t onesweep_tile_temp_bytes(int R, int end_bit) { return os_temp_bytes<uint16_t>((size_t)(R > 0 ? R : 1), end_bit); }
+size_t onesweep_tile_temp_bytes(int R, int end_bit, int key_bytes)
+{
+    return key_bytes == 4 ? os_temp_bytes<uint32_t>((size_t)(R > 0 ? R : 1), end_bit) : os_temp_bytes<uint16_t>((size_t)(R > 0 ? R : 1), end_bit);
+}
+hipError_t onesweep_tile_sort32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                                int R, int end_bit, hipStream_t s)
+{
+    return os_sort<uint32_t>(temp, temp_bytes, kin, kout, vin, vout, (size_t)R, end_bit, s);
+}
 hipError_t onesweep_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
                                int P, const uint2* gather_src, uint2* gather_dst, hipStream_t s)
 {

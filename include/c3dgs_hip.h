@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define C3DGS_ABI_VERSION 3
+#define C3DGS_ABI_VERSION 4
 
 enum {
     C3DGS_OK = 0,
@@ -376,6 +376,7 @@ typedef struct c3dgs_image_layout {   /* byte offsets into the image buffer     
     size_t n_contrib;  /* uint32[W*H]                                                      */
     size_t ranges;     /* uint32[2*T]                                                      */
     size_t tile_used;  /* uint32[T] max n_contrib over the tile's pixels                   */
+    size_t tile_order; /* uint32[T] scratch of the backward: its tile schedule (ABI version 4)  */
 } c3dgs_image_layout;
 
 /* tests only: the binning stage's stable LSD radix sort (radix_sort.hip) on caller-provided pairs. key_bytes = 2 (tile

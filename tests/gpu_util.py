@@ -96,8 +96,12 @@ def unpack(fw):
         b = fw["binning"]
         # the library keeps 16-bit tile keys; the reference's 64-bit key is (tile << 32) | depth bits of the Gaussian
         dbits = out["depths"].view(np.uint32).astype(np.uint64)
-        tk_u = _view(b, bl.keys_unsorted, R, torch.int16).cpu().numpy().view(np.uint16).astype(np.uint64)
-        tk_s = _view(b, bl.keys_sorted, R, torch.int16).cpu().numpy().view(np.uint16).astype(np.uint64)
+        if T > 65536:                                     # more than 65,536 tiles: the library switches to 32-bit tile keys
+            tk_u = _view(b, bl.keys_unsorted, R, torch.int32).cpu().numpy().view(np.uint32).astype(np.uint64)
+            tk_s = _view(b, bl.keys_sorted, R, torch.int32).cpu().numpy().view(np.uint32).astype(np.uint64)
+        else:
+            tk_u = _view(b, bl.keys_unsorted, R, torch.int16).cpu().numpy().view(np.uint16).astype(np.uint64)
+            tk_s = _view(b, bl.keys_sorted, R, torch.int16).cpu().numpy().view(np.uint16).astype(np.uint64)
         out["values_unsorted"] = _view(b, bl.values_unsorted, R, torch.int32).cpu().numpy().view(np.uint32)
         out["point_list"] = _view(b, bl.point_list, R, torch.int32).cpu().numpy().view(np.uint32)
         out["keys_unsorted"] = (tk_u << np.uint64(32)) | dbits[out["values_unsorted"]]

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/c3dgs_hip.h but not exported"
         assert s in _lib.PROTOTYPES, f"{s} has no ctypes prototype"
-    assert L.c3dgs_abi_version() == 3
+    assert L.c3dgs_abi_version() == 4
 
 
 def test_layouts_are_consistent(L):
@@ -77,15 +77,33 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.lib()
 
 
-def test_image_larger_than_the_16_bit_tile_keys_is_rejected(L):
+def test_image_size_limits(L):
+    """More than 65,536 tiles is no longer a limit (32-bit tile keys take over, tests/test_raster_gpu.py::test_8k_image_...); what is
+    rejected up front: tile coordinates beyond 16 bits and (tiles per row)^2 x (tile rows) >= 2^32 (the pair emission's exact
+    multiply-high division). Checked without a GPU: validation runs before any launch, the callbacks refuse to allocate."""
     from c3dgs_amd import _lib
-    p = _lib.RasterParams()
-    p.P, p.W, p.H = 4, 7680, 4320                        # 480 x 270 = 129600 tiles
     one = (C.c_float * 16)()
-    for name in ("background", "means3D", "sh", "opacities", "scales", "rotations", "viewmatrix", "projmatrix", "campos"):
-        setattr(p, name, C.addressof(one))
-    p.M, p.D = 16, 3
-    n = C.c_int32(0)
-    cb = _lib.RESIZE_FN(lambda u, b: 0)
-    rc = L.c3dgs_rasterize_gaussians(C.byref(p), cb, None, cb, None, cb, None, C.addressof(one), C.addressof(one), C.byref(n), None)
-    assert rc == 1 and b"65536 tiles" in L.c3dgs_last_error()
+
+    def call(W, H):
+        p = _lib.RasterParams()
+        p.P, p.W, p.H = 4, W, H
+        for name in ("background", "means3D", "sh", "opacities", "scales", "rotations", "viewmatrix", "projmatrix", "campos"):
+            setattr(p, name, C.addressof(one))
+        p.M, p.D = 16, 3
+        n = C.c_int32(0)
+        cb = _lib.RESIZE_FN(lambda u, b: 0)
+        rc = L.c3dgs_rasterize_gaussians(C.byref(p), cb, None, cb, None, cb, None, C.addressof(one), C.addressof(one), C.byref(n), None)
+        return rc, L.c3dgs_last_error()
+
+    rc, msg = call(7680, 4320)                           # 480 x 270 = 129,600 tiles: accepted (fails later, at the refused allocation)
+    assert rc != 0 and b"allocation failed" in msg, msg
+    rc, msg = call(40_000, 30_000)                       # 2500^2 x 1875 tiles^3 > 2^32
+    assert rc == 1 and b"image too large" in msg, msg
+    rc, msg = call(16 * 65536, 16)
+    assert rc == 1 and b"16-bit tile coordinates" in msg, msg
+    il = _lib.ImageLayout()
+    assert L.c3dgs_get_image_layout(7680, 4320, C.byref(il)) == 0 and il.tile_order >= il.tile_used + 4 * 129_600
+    b2, b4 = _lib.BinningLayout(), _lib.BinningLayout()
+    L.c3dgs_get_binning_layout(1000, 4096, 4096, C.byref(b2))        # 65,536 tiles: 16-bit keys
+    L.c3dgs_get_binning_layout(1000, 4112, 4096, C.byref(b4))        # 65,792 tiles: 32-bit keys
+    assert b2.values_unsorted - b2.keys_unsorted < b4.values_unsorted - b4.keys_unsorted

@@ -234,3 +234,35 @@ def test_hip_backward_vs_reference_autograd_fixtures(hip, orc, mod, deg):
     want_q = np.einsum("pk,pkc->pc", dcov, cv[f"jac_rot_mod{mod}"].astype(np.float64))
     assert gpu_util.rel_inf(tang, want_q) <= 1e-4
     assert np.abs(want_q).max() > 0 and np.abs(want_s).max() > 0
+
+
+def test_8k_image_with_32_bit_tile_keys_matches_the_oracle(hip, orc):
+    """7680x4320 = 480 x 270 = 129,600 tiles: beyond the 65,536 that 16-bit tile keys can name, the library switches to 32-bit
+    keys (three digit passes of the tile sort), as the reference's 64-bit keys allow (rasterizer_impl.cu:98-108). Against the
+    oracle on the same inputs: radii, the (tile << 32 | depth) keys, the sorted point list and the ranges equal, image PSNR >= 80 dB,
+    gradients within the flip-aware bars. A few thousand Gaussians keep the oracle's 33-Mpixel view at a few seconds; some of them
+    are made screen-filling so that rectangles of tens of thousands of tiles (the emission's division) are exercised."""
+    W, H, focal, P = 7680, 4320, 4800.0, 6000
+    intr, ev = synth.camera(W, H, focal)
+    cam = orc.camera(intr.numpy(), ev.numpy())
+    sc = synth.scene(P, W, H, focal, seed=81, scale_median=0.02)
+    sc["scales"][:12] *= 60.0                                    # a dozen splats thousands of pixels wide
+    sc["opacities"][:12] = 0.05
+    inp = dict(bg=torch.tensor([0.1, 0.0, 0.2]), means3D=sc["means3D"], opacities=sc["opacities"], shs=sc["shs"], colors_precomp=None,
+               scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None, scale_factors=None, sh_indices=None, g_indices=None,
+               degree=3, scale_modifier=1.0, prefiltered=False, clamp_color=True)
+    st = cases.oracle_forward(inp, cam)
+    assert st.T == 129_600 and st.num_rendered > 100_000
+    fw = gpu_util.hip_forward(inp, cam, False)
+    u = gpu_util.unpack(fw)
+    assert u["num_rendered"] == st.num_rendered
+    np.testing.assert_array_equal(u["radii"], st.radii)
+    np.testing.assert_array_equal(u["keys_sorted"], st.keys_sorted)
+    assert int(st.keys_sorted[-1] >> np.uint64(32)) > 65535      # tile ids beyond 16 bits are in use
+    np.testing.assert_array_equal(u["point_list"], st.point_list)
+    np.testing.assert_array_equal(u["ranges"], st.ranges)
+    assert gpu_util.psnr(u["out_color"], st.out_color) >= 80.0
+    dL = synth.grad_image(W, H).numpy()
+    ref = orc.rasterize_backward(st, dL)
+    got = gpu_util.hip_backward(fw, dL)
+    fullsize.check_grads(st, u, got, ref, GRAD_TOL, "8k")
