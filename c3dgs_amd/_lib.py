@@ -71,6 +71,7 @@ _vp = C.c_void_p
 PROTOTYPES = {
     "c3dgs_camera_from_pose": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c3dgs_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c3dgs_mark_visible_pose": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c3dgs_rasterize_gaussians": (C.c_int, [C.POINTER(RasterParams), RESIZE_FN, C.c_void_p, RESIZE_FN, C.c_void_p,
                                             RESIZE_FN, C.c_void_p, C.c_void_p, C.c_void_p, _i32p, C.c_void_p]),
     "c3dgs_rasterize_gaussians_indexed": (C.c_int, [C.POINTER(RasterParams), RESIZE_FN, C.c_void_p, RESIZE_FN, C.c_void_p,

@@ -57,11 +57,20 @@ gather_u64_kernel(int n, const uint32_t* __restrict__ idx, const uint2* __restri
 // sorts (depth bits, id) and also delivers `rects_sorted[k]` = tile rectangle of the k-th nearest Gaussian (the one
 // per-Gaussian record the pair emission needs): the hand-written sort gathers it while scattering its last digit pass,
 // the rocPRIM path with one extra kernel
+size_t depth_sort_clear_bytes(int P)
+{
+    return (onesweep_enabled() && (size_t)P < ((size_t)1 << 30)) ? onesweep_depth_clear_bytes(P) : 0;
+}
+size_t tile_sort_clear_bytes(int R, int end_bit, int key_bytes)
+{
+    return (onesweep_enabled() && (size_t)R < ((size_t)1 << 30)) ? onesweep_tile_clear_bytes(R, end_bit, key_bytes) : 0;
+}
+
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
-                          uint32_t* vout, int P, const uint2* rects, uint2* rects_sorted, hipStream_t s)
+                          uint32_t* vout, int P, const uint2* rects, uint2* rects_sorted, hipStream_t s, bool ctrl_cleared)
 {
     if (onesweep_enabled() && (size_t)P < ((size_t)1 << 30))
-        return onesweep_depth_sort(temp, temp_bytes, kin, kout, vin, vout, P, rects, rects_sorted, s);
+        return onesweep_depth_sort(temp, temp_bytes, kin, kout, vin, vout, P, rects, rects_sorted, s, ctrl_cleared);
     // vin == nullptr: the payload is the Gaussian id itself (0 .. P-1)
     hipError_t e = vin ? rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 0u, 32u, s)
                        : rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, rocprim::counting_iterator<uint32_t>(0u), vout,
@@ -72,15 +81,15 @@ hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, ui
 }
 
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, const void* kin, void* kout, int key_bytes, const uint32_t* vin,
-                         uint32_t* vout, int R, int end_bit, hipStream_t s)
+                         uint32_t* vout, int R, int end_bit, hipStream_t s, bool ctrl_cleared)
 {
     if (key_bytes == 4) {       // more than 65,536 tiles: 32-bit tile keys, three digit passes for 17-24 tile bits
         if (onesweep_enabled() && (size_t)R < ((size_t)1 << 30))
-            return onesweep_tile_sort32(temp, temp_bytes, (const uint32_t*)kin, (uint32_t*)kout, vin, vout, R, end_bit, s);
+            return onesweep_tile_sort32(temp, temp_bytes, (const uint32_t*)kin, (uint32_t*)kout, vin, vout, R, end_bit, s, ctrl_cleared);
         return rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t*)kin, (uint32_t*)kout, vin, vout, (size_t)R, 0u, (unsigned)end_bit, s);
     }
     if (onesweep_enabled() && (size_t)R < ((size_t)1 << 30))
-        return onesweep_tile_sort(temp, temp_bytes, (const uint16_t*)kin, (uint16_t*)kout, vin, vout, R, end_bit, s);
+        return onesweep_tile_sort(temp, temp_bytes, (const uint16_t*)kin, (uint16_t*)kout, vin, vout, R, end_bit, s, ctrl_cleared);
     return rocprim::radix_sort_pairs(temp, temp_bytes, (const uint16_t*)kin, (uint16_t*)kout, vin, vout, (size_t)R, 0u, (unsigned)end_bit, s);
 }
 

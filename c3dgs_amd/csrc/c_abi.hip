@@ -2,6 +2,8 @@
 // Stage order follows the reference's Rasterizer::forward / backward (cuda_rasterizer/rasterizer_impl.cu:194-334,
 // 338-435, 440-586, 590-697); the stages themselves are the gfx950 kernels in this directory.
 #include "common.hpp"
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -50,14 +52,29 @@ struct StageTimer {
     }
 };
 
-// pinned 4-byte landing pad + event for the forward's single device->host read (one per calling thread)
+// Landing pad of the forward's single device->host read (one per calling thread): 64 bytes of page-locked host memory. When
+// the allocation can be MAPPED into the device's address space (coherent, fine-grained: the normal case), the kernel that
+// produces num_rendered stores {num_rendered, sort error word, sequence number} straight into it and the host polls the
+// sequence number -- no copy command on the stream (a ~4 us launch + a ~6 us bubble per forward). Otherwise (`dev` null):
+// a hipMemcpyAsync into it behind an event, as before.
 struct HostRead {
     uint32_t* pinned = nullptr;
+    uint32_t* dev = nullptr;      // device-side address of `pinned`, or null
+    uint32_t seq = 0;
     hipEvent_t ev{};
     HostRead()
     {
-        if (hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault) != hipSuccess) { pinned = nullptr; return; }
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(pinned); pinned = nullptr; }
+        const char* e = std::getenv("C3DGS_HOST_READ_COPY");            // "1": force the copy path (test / diagnosis)
+        const bool want_map = !(e && e[0] == '1');
+        if (want_map && hipHostMalloc((void**)&pinned, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) == hipSuccess) {
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, pinned, 0) == hipSuccess) dev = (uint32_t*)d;
+            std::memset(pinned, 0, 64);
+        } else {
+            (void)hipGetLastError();
+            if (hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault) != hipSuccess) { pinned = nullptr; return; }
+        }
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(pinned); pinned = nullptr; dev = nullptr; }
     }
 };
 static HostRead& host_read()
@@ -135,29 +152,55 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     // K2 / K2i, with the id-order scan of tiles_touched folded in (per-workgroup offsets + block_base[])
     uint32_t* sort_err = onesweep_error_word();
     if (!sort_err) return fail(C3DGS_E_HIP, "cannot resolve the sort error word");
+    HostRead& hr = host_read();
+    if (!hr.pinned) return fail(C3DGS_E_HIP, "pinned host buffer allocation failed");
+    const uint32_t seq = hr.dev ? ++hr.seq : 0u;
+    if (hr.dev && seq == 0u) hr.seq = 1u;                                // (wrap-around: 0 is the pad's initial value)
+    const uint32_t want_seq = hr.dev ? hr.seq : 0u;
+    // the depth sort's control words are cleared by preprocess's workgroups (0 bytes: that sort clears its own)
+    const size_t dclear = depth_sort_clear_bytes(P) <= g.scan_temp_bytes ? depth_sort_clear_bytes(P) : 0;
     { StageTimer t_(ST_PREPROCESS, s);
       if (geom_gtab_bytes(p)) launch_pack_codebook(p, g.gtab, s);
-      launch_preprocess(p, g, radii, img.ranges, sort_err, s); }
+      launch_preprocess(p, g, radii, img.ranges, sort_err, g.scan_temp, dclear / 16, hr.dev, want_seq, s); }
     C3DGS_STAGE("preprocess", p.debug, s);
     // The one device->host read of the forward (K4, num_rendered) is issued as EARLY as its value exists: R is the last
     // entry of block_base[]. The copy lands in pinned memory behind an event while the depth sort and the depth-order
     // scan are already queued, so the GPU keeps working while the host waits, sizes the binning buffer and queues the
     // rest (the reference blocks the stream at this point, rasterizer_impl.cu:279).
-    HostRead& hr = host_read();
-    if (!hr.pinned) return fail(C3DGS_E_HIP, "pinned host buffer allocation failed");
     // second word: the device's sticky sort time-out flag as of the start of this call (radix_sort.hip)
-    C3DGS_HIP_TRY(hipMemcpyAsync(hr.pinned, g.block_base + (P + 255) / 256, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    C3DGS_HIP_TRY(hipEventRecord(hr.ev, s));
+    if (!hr.dev) {
+        C3DGS_HIP_TRY(hipMemcpyAsync(hr.pinned, g.block_base + (P + 255) / 256, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        C3DGS_HIP_TRY(hipEventRecord(hr.ev, s));
+    }
     { StageTimer t_(ST_DEPTH_SORT, s);                                               // binning stage 1: P Gaussians by depth
       C3DGS_HIP_TRY(run_depth_sort(g.scan_temp, g.scan_temp_bytes, g.depth_keys, g.depth_keys_sorted, nullptr, g.depth_order, P,
-                                   reinterpret_cast<const uint2*>(g.rects), g.sorted_offsets, s)); }
+                                   reinterpret_cast<const uint2*>(g.rects), g.sorted_offsets, s, dclear != 0)); }
     C3DGS_STAGE("depth_sort", p.debug, s);
     if (p.debug && onesweep_timed_out(s)) return fail(C3DGS_E_HIP, "depth sort: look-back timed out");
     { StageTimer t_(ST_SCAN, s); launch_depth_order_scan(P, g, s); }                 // K3, in depth order (two-level)
     C3DGS_STAGE("scan", p.debug, s);
     // Poll instead of sleeping in the driver: on a busy host the wake-up from a blocking event wait can take
     // milliseconds (seen as a 2x slower step with unchanged kernel times); the copy is normally done within ~100 us.
-    {
+    if (hr.dev) {
+        // mapped pad: wait for this call's sequence number. Every ~64k polls the stream is queried as well: if it has drained
+        // (or failed) and the number still is not there, the store never became visible -> fetch the two words with a copy
+        volatile uint32_t* pad = hr.pinned;
+        bool seen = false;
+        for (long spins = 0; !seen; spins++) {
+            seen = __atomic_load_n(&pad[2], __ATOMIC_ACQUIRE) == want_seq;
+            if (!seen && (spins & 0xffff) == 0xffff) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipErrorNotReady) continue;
+                if (q != hipSuccess) return fail(C3DGS_E_HIP, std::string("num_rendered read: ") + hipGetErrorString(q));
+                seen = __atomic_load_n(&pad[2], __ATOMIC_ACQUIRE) == want_seq;
+                if (!seen) {
+                    C3DGS_HIP_TRY(hipMemcpyAsync(hr.pinned, g.block_base + (P + 255) / 256, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    C3DGS_HIP_TRY(hipStreamSynchronize(s));
+                    seen = true;
+                }
+            }
+        }
+    } else {
         hipError_t q = hipErrorNotReady;
         for (long spins = 0; spins < 20000000L && (q = hipEventQuery(hr.ev)) == hipErrorNotReady; spins++) { }
         if (q == hipErrorNotReady) q = hipEventSynchronize(hr.ev);
@@ -181,12 +224,15 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     const BinPtrs b = bin_ptrs(bin_base, R, W, H);
 
     if (R > 0) {
-        { StageTimer t_(ST_DUPLICATE, s); launch_duplicate_with_keys(P, g, b, gx, sort_err, s); } // K5
-        C3DGS_STAGE("duplicate_with_keys", p.debug, s);
         const int end_bit = (int)higher_msb((uint32_t)T);                           // tile bits only (rasterizer_impl.cu:298)
+        // the tile sort's control words are cleared by the pair emission's workgroups (0 bytes: that sort clears its own)
+        size_t tclear = tile_sort_clear_bytes(R, end_bit, b.key_bytes);
+        if (tclear > b.sort_temp_bytes) tclear = 0;
+        { StageTimer t_(ST_DUPLICATE, s); launch_duplicate_with_keys(P, g, b, gx, sort_err, b.sort_temp, tclear / 16, s); } // K5
+        C3DGS_STAGE("duplicate_with_keys", p.debug, s);
         { StageTimer t_(ST_SORT, s);
           C3DGS_HIP_TRY(run_tile_sort(b.sort_temp, b.sort_temp_bytes, b.keys_unsorted, b.keys_sorted, b.key_bytes, b.values_unsorted,
-                                      b.point_list, R, end_bit, s)); }               // K6, binning stage 2
+                                      b.point_list, R, end_bit, s, tclear != 0)); }  // K6, binning stage 2
         C3DGS_STAGE("sort", p.debug, s);
         if (p.debug && onesweep_timed_out(s)) return fail(C3DGS_E_HIP, "tile sort: look-back timed out");
         { StageTimer t_(ST_RANGES, s); launch_identify_ranges(R, b.keys_sorted, b.key_bytes, img.ranges, sort_err, s); } // K8
@@ -416,6 +462,16 @@ int c3dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
     if (P == 0) return C3DGS_OK;
     if (!means3D || !viewmatrix || !present) return fail(C3DGS_E_INVALID, "means3D, viewmatrix and present are required");
     { StageTimer t_(ST_MARK_VISIBLE, (hipStream_t)stream); launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream); }
+    C3DGS_STAGE("mark_visible", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
+int c3dgs_mark_visible_pose(int32_t P, const float* means3D, const float* extrinsic_vector, uint8_t* present, void* stream)
+{
+    if (P < 0) return fail(C3DGS_E_INVALID, "P must be >= 0");
+    if (P == 0) return C3DGS_OK;
+    if (!means3D || !extrinsic_vector || !present) return fail(C3DGS_E_INVALID, "means3D, extrinsic_vector and present are required");
+    { StageTimer t_(ST_MARK_VISIBLE, (hipStream_t)stream); launch_mark_visible_pose(P, means3D, extrinsic_vector, present, (hipStream_t)stream); }
     C3DGS_STAGE("mark_visible", 0, (hipStream_t)stream);
     return C3DGS_OK;
 }

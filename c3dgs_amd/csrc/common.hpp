@@ -152,28 +152,39 @@ inline ImgPtrs img_ptrs(void* base, int W, int H)
 // preprocess.hip
 void launch_camera_from_pose(const float* pose, float inv_tan_x, float inv_tan_y, float* view, float* proj, float* campos, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+void launch_mark_visible_pose(int P, const float* means3D, const float* pose7, uint8_t* present, hipStream_t s);
 void launch_pack_codebook(const c3dgs_raster_params& p, float4* gtab, hipStream_t s);
-void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, const uint32_t* sort_err, hipStream_t s);
+// zero_span / zero_n16: 16-byte words every workgroup clears a slice of before anything else (the depth sort's control words);
+// host_out / host_seq: mapped host words {num_rendered, sort error flag, host_seq} the closing scan writes (or null)
+void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, const uint32_t* sort_err,
+                       void* zero_span, size_t zero_n16, uint32_t* host_out, uint32_t host_seq, hipStream_t s);
 void launch_depth_order_scan(int P, const GeomPtrs& g, hipStream_t s);   // block totals of tiles_sorted -> depth_base[]
-void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, const uint32_t* sort_err, hipStream_t s);
+void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, const uint32_t* sort_err,
+                                void* zero_span, size_t zero_n16, hipStream_t s);   // zero span: the tile sort's control words
 void launch_identify_ranges(int R, const void* keys_sorted, int key_bytes, uint2* ranges, const uint32_t* sort_err, hipStream_t s);
 // binning.hip
+// ctrl_cleared: the first *_sort_clear_bytes(...) bytes of `temp` were zeroed by an earlier kernel on the same stream
+// (0 bytes = this configuration's sort clears its own control words: pass false)
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
-                          uint32_t* vout, int P, const uint2* rects, uint2* rects_sorted, hipStream_t s);
+                          uint32_t* vout, int P, const uint2* rects, uint2* rects_sorted, hipStream_t s, bool ctrl_cleared = false);
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, const void* kin, void* kout, int key_bytes, const uint32_t* vin,
-                         uint32_t* vout, int R, int end_bit, hipStream_t s);
+                         uint32_t* vout, int R, int end_bit, hipStream_t s, bool ctrl_cleared = false);
+size_t depth_sort_clear_bytes(int P);
+size_t tile_sort_clear_bytes(int R, int end_bit, int key_bytes);
 // radix_sort.hip (hand-written onesweep; C3DGS_SORT_ROCPRIM=1 selects the rocPRIM path of binning.hip instead)
 bool onesweep_enabled();
 int onesweep_timed_out(hipStream_t s);   // debug mode only (synchronises): reads + clears the sticky error word
 uint32_t* onesweep_error_word();          // device address of the sticky look-back time-out word (0 = fine)
 size_t onesweep_depth_temp_bytes(int P);
 size_t onesweep_tile_temp_bytes(int R, int end_bit, int key_bytes = 2);
+size_t onesweep_depth_clear_bytes(int P);
+size_t onesweep_tile_clear_bytes(int R, int end_bit, int key_bytes);
 hipError_t onesweep_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
-                               int P, const uint2* gather_src, uint2* gather_dst, hipStream_t s);
+                               int P, const uint2* gather_src, uint2* gather_dst, hipStream_t s, bool ctrl_cleared = false);
 hipError_t onesweep_tile_sort32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
-                                int R, int end_bit, hipStream_t s);   // 32-bit tile keys (more than 65,536 tiles)
+                                int R, int end_bit, hipStream_t s, bool ctrl_cleared = false);   // 32-bit tile keys (more than 65,536 tiles)
 hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin, uint32_t* vout,
-                              int R, int end_bit, hipStream_t s);
+                              int R, int end_bit, hipStream_t s, bool ctrl_cleared = false);
 // render.hip
 int os_read_times(unsigned long long* out512);   // radix_sort.hip, experiment builds with -DC3DGS_OS_TIMING only
 int read_lane_counters(unsigned long long* out16, hipStream_t s);   // render.hip; all zero unless built with -DC3DGS_COUNT_LANES

@@ -22,12 +22,27 @@ namespace c3dgs {
 // four Gaussians per thread: 48 bytes of positions as three 16-byte loads, four flags as one 4-byte store (a thread per
 // Gaussian with three 4-byte loads and a 1-byte store: 12-14 us for P = 3M; the pointers are 16- / 4-byte aligned when
 // they come from torch allocations, anything else takes the scalar tail)
+// POSE: `view` is the camera's 7-element pose (qx, qy, qz, qw, tx, ty, tz) instead of the 4x4 matrix; every thread forms the
+// matrix entries the test reads (column 2 of the transposed view = row 2 of world->camera) with the fp32 operations of
+// camera_from_pose_kernel below, in the same order (this file is built with -ffp-contract=off): same bits as the matrix path
+// without that single-thread launch in front (5 us of an idle GPU per call).
+template <bool POSE>
 __global__ void __launch_bounds__(256)
-mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view, uint8_t* __restrict__ present, int vec)
+mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view_or_pose, uint8_t* __restrict__ present, int vec)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int i0 = 4 * j;
     if (i0 >= P) return;
+    float vm[16];
+    const float* view = view_or_pose;
+    if (POSE) {
+        const float x = view_or_pose[0], y = view_or_pose[1], z = view_or_pose[2], w = view_or_pose[3], tz = view_or_pose[6];
+        const float d2 = y * y + z * z + x * x;
+#pragma unroll
+        for (int q = 0; q < 16; q++) vm[q] = 0.f;
+        vm[2] = 2.0f * (x * z - w * y); vm[6] = 2.0f * (y * z + w * x); vm[10] = 1.0f + 2.0f * (z * z - d2); vm[14] = tz;
+        view = vm;
+    }
     if (vec && i0 + 4 <= P) {
         const float4* src = reinterpret_cast<const float4*>(means3D) + 3 * (size_t)j;
         const float4 a = src[0], b = src[1], c = src[2];
@@ -63,7 +78,14 @@ void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t
 {
     if (P <= 0) return;
     const int vec = ((reinterpret_cast<uintptr_t>(means3D) & 15u) == 0 && (reinterpret_cast<uintptr_t>(present) & 3u) == 0) ? 1 : 0;
-    mark_visible_kernel<<<((P + 3) / 4 + 255) / 256, 256, 0, s>>>(P, means3D, view, present, vec);
+    mark_visible_kernel<false><<<((P + 3) / 4 + 255) / 256, 256, 0, s>>>(P, means3D, view, present, vec);
+}
+
+void launch_mark_visible_pose(int P, const float* means3D, const float* pose, uint8_t* present, hipStream_t s)
+{
+    if (P <= 0) return;
+    const int vec = ((reinterpret_cast<uintptr_t>(means3D) & 15u) == 0 && (reinterpret_cast<uintptr_t>(present) & 3u) == 0) ? 1 : 0;
+    mark_visible_kernel<true><<<((P + 3) / 4 + 255) / 256, 256, 0, s>>>(P, means3D, pose, present, vec);
 }
 
 // ---- camera set-up ON THE DEVICE, from the pose's live values: the host part of the reference's autograd wrappers
@@ -153,6 +175,7 @@ struct PreArgs {
     uint32_t* inst_offset; uint32_t* block_total;   // two-level id-order scan
     uint2* ranges; int T;                            // tile ranges, cleared here for identify_ranges (K7)
     const float4* gtab;                              // packed scale / rotation codebook (indexed variant)
+    uint4* zero_span; size_t zero_n16;               // the depth sort's control words, cleared here (a slice per workgroup)
 };
 
 // The id-order scan of tiles_touched (where a Gaussian's backward partial-sum slots live; its total is num_rendered) is
@@ -168,6 +191,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
     const int i = blockIdx.x * 256 + t;
     const bool in_range = i < a.P;
     for (int q = i; q < a.T; q += gridDim.x * 256) a.ranges[q] = make_uint2(0u, 0u);   // replaces a memset launch (rasterizer_impl.cu:308)
+    if (a.zero_n16) {                                                                   // ... and the depth sort's own fill launch
+        const size_t per = (a.zero_n16 + gridDim.x - 1) / gridDim.x, z0 = (size_t)blockIdx.x * per, z1 = min(z0 + per, a.zero_n16);
+        for (size_t q = z0 + t; q < z1; q += 256) a.zero_span[q] = make_uint4(0u, 0u, 0u, 0u);
+    }
 
     int32_t out_radius = 0;
     uint32_t out_tiles = 0;
@@ -290,7 +317,11 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
 // base[nb] = num_rendered. One workgroup; nb = P/256 is a few thousand to a few ten-thousand.
 // `sort_err` (optional): the device's sticky sort time-out word, copied behind the total so that the forward's single
 // device->host read of num_rendered brings it along (radix_sort.hip).
-__global__ void __launch_bounds__(1024) scan_blocks_kernel(int nb, uint32_t* __restrict__ base, const uint32_t* __restrict__ sort_err)
+// `host_out` (optional): three words of MAPPED, coherent host memory {total, sort error word, host_seq}: the forward's one
+// device->host read without a copy command -- the host polls the third word for `host_seq` (c_abi.hip). A copy command behind
+// this kernel cost a 4 us launch of its own plus a ~6 us bubble on the stream.
+__global__ void __launch_bounds__(1024) scan_blocks_kernel(int nb, uint32_t* __restrict__ base, const uint32_t* __restrict__ sort_err,
+                                                           uint32_t* __restrict__ host_out, uint32_t host_seq)
 {
     // One workgroup; a thread owns 16 CONSECUTIVE totals (four independent 16-byte loads), so 16384 totals cost one
     // memory round trip and one barrier. (One total per thread and a round trip + barrier per 1024 totals took 12 us for the
@@ -341,11 +372,18 @@ __global__ void __launch_bounds__(1024) scan_blocks_kernel(int nb, uint32_t* __r
     __syncthreads();                                      // the last sweep's stores precede the two words behind them
     if (t == 0) {
         base[nb] = carry;
-        if (sort_err) base[nb + 1] = *sort_err;
+        const uint32_t err = sort_err ? *sort_err : 0u;
+        if (sort_err) base[nb + 1] = err;
+        if (host_out) {
+            __hip_atomic_store(host_out, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_out + 1, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_out + 2, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // publishes the two words above
+        }
     }
 }
 
-void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, const uint32_t* sort_err, hipStream_t s)
+void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t* radii, uint2* ranges, const uint32_t* sort_err,
+                       void* zero_span, size_t zero_n16, uint32_t* host_out, uint32_t host_seq, hipStream_t s)
 {
     if (p.P <= 0) return;
     PreArgs a;
@@ -364,6 +402,7 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
     a.block_total = g.block_base;     // totals in, exclusive bases out (scan_blocks_kernel)
     a.ranges = ranges; a.T = a.gx * a.gy;
     a.gtab = g.gtab;
+    a.zero_span = (uint4*)zero_span; a.zero_n16 = zero_span ? zero_n16 : 0;
     const dim3 grid((p.P + 255) / 256), block(256);
     const int deg = p.colors_precomp ? 0 : p.D;
     switch (deg) {
@@ -372,7 +411,7 @@ void launch_preprocess(const c3dgs_raster_params& p, const GeomPtrs& g, int32_t*
         case 2: preprocess_kernel<2><<<grid, block, 0, s>>>(a); break;
         default: preprocess_kernel<3><<<grid, block, 0, s>>>(a); break;
     }
-    scan_blocks_kernel<<<1, 1024, 0, s>>>((int)grid.x, g.block_base, sort_err);
+    scan_blocks_kernel<<<1, 1024, 0, s>>>((int)grid.x, g.block_base, sort_err, host_out, host_seq);
 }
 
 // ---- K5: one (tile, Gaussian) pair per Gaussian x tile, reference rasterizer_impl.cu:70-111, walked in
@@ -404,8 +443,14 @@ template <class K>   // tile key type: uint16_t, or uint32_t above 65,536 tiles
 __global__ void __launch_bounds__(256)
 duplicate_with_keys_kernel(int P, const uint32_t* __restrict__ order, const uint2* __restrict__ rects_sorted,
                            const uint32_t* __restrict__ depth_base, K* __restrict__ keys, uint32_t* __restrict__ values,
-                           int grid_x, const uint32_t* __restrict__ sort_err)
+                           int grid_x, const uint32_t* __restrict__ sort_err, uint4* __restrict__ zero_span, size_t zero_n16)
 {
+    // the tile sort's control words (look-back status, tickets) are cleared here, a slice per workgroup, instead of by a fill
+    // launch in front of the sort -- BEFORE the early-out below: that sort runs either way and must not walk stale status words
+    if (zero_n16) {
+        const size_t per = (zero_n16 + gridDim.x - 1) / gridDim.x, z0 = (size_t)blockIdx.x * per, z1 = min(z0 + per, zero_n16);
+        for (size_t q = z0 + threadIdx.x; q < z1; q += 256) zero_span[q] = make_uint4(0u, 0u, 0u, 0u);
+    }
     // a depth sort whose look-back gave up (radix_sort.hip) left positions of `order` / `rects_sorted` unwritten: their stale
     // contents would be emission offsets -> never dereference them (the image is poisoned by render_forward, the host reports)
     if (*sort_err) return;
@@ -508,18 +553,20 @@ void launch_depth_order_scan(int P, const GeomPtrs& g, hipStream_t s)
     if (P <= 0) return;
     const int nb = (P + 255) / 256;
     block_totals_kernel<<<nb, 256, 0, s>>>(P, g.sorted_offsets, g.depth_base);
-    scan_blocks_kernel<<<1, 1024, 0, s>>>(nb, g.depth_base, nullptr);
+    scan_blocks_kernel<<<1, 1024, 0, s>>>(nb, g.depth_base, nullptr, nullptr, 0u);
 }
 
-void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, const uint32_t* sort_err, hipStream_t s)
+void launch_duplicate_with_keys(int P, const GeomPtrs& g, const BinPtrs& b, int grid_x, const uint32_t* sort_err,
+                                void* zero_span, size_t zero_n16, hipStream_t s)
 {
     if (P <= 0) return;
+    if (!zero_span) zero_n16 = 0;
     if (b.key_bytes == 4)
         duplicate_with_keys_kernel<uint32_t><<<(P + 255) / 256, 256, 0, s>>>(P, g.depth_order, g.sorted_offsets, g.depth_base,
-                                                                             (uint32_t*)b.keys_unsorted, b.values_unsorted, grid_x, sort_err);
+                                                                             (uint32_t*)b.keys_unsorted, b.values_unsorted, grid_x, sort_err, (uint4*)zero_span, zero_n16);
     else
         duplicate_with_keys_kernel<uint16_t><<<(P + 255) / 256, 256, 0, s>>>(P, g.depth_order, g.sorted_offsets, g.depth_base,
-                                                                             (uint16_t*)b.keys_unsorted, b.values_unsorted, grid_x, sort_err);
+                                                                             (uint16_t*)b.keys_unsorted, b.values_unsorted, grid_x, sort_err, (uint4*)zero_span, zero_n16);
 }
 
 // ---- K8: reference rasterizer_impl.cu:116-138 (ranges pre-zeroed by the caller, :308)

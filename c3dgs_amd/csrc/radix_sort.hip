@@ -379,9 +379,22 @@ static size_t os_temp_bytes(size_t n, int total_bits)
     return b;
 }
 
+// the control words at the front of `temp` that must be ZERO when the sort starts (digit histograms the histogram kernel adds
+// into, look-back status words, tickets). os_sort clears them itself unless the caller says a kernel it ran just before on the
+// same stream already did (`ctrl_cleared`: the rasterizer folds the two clears of a forward into preprocess / duplicate_with_keys,
+// whose thousands of workgroups do it for free -- a separate fill launch costs ~5 us of an otherwise idle GPU each)
+template <class K>
+static size_t os_clear_bytes(size_t n, int total_bits)
+{
+    const OsPlan plan = os_plan(total_bits);
+    if (!os_pre_pass0<K>()) return os_ctrl_bytes<K>(n, plan.passes);
+    return ((size_t)plan.passes * OS_RADIX + (size_t)plan.passes * os_blocks<K>(n) * OS_RADIX + 64) * sizeof(uint32_t);   // the table behind is written in full
+}
+
 template <class K>
 static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, size_t n,
-                          int total_bits, hipStream_t s, const uint2* gather_src = nullptr, uint2* gather_dst = nullptr)
+                          int total_bits, hipStream_t s, const uint2* gather_src = nullptr, uint2* gather_dst = nullptr,
+                          bool ctrl_cleared = false)
 {
     if (n == 0) return hipSuccess;
     if (n >= ((size_t)1 << 30) || os_temp_bytes<K>(n, total_bits) > temp_bytes) return hipErrorInvalidValue;
@@ -398,8 +411,10 @@ static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, 
     char* q = base + ctrl;
     for (int i = 0; i < 2; i++) { tk[i] = (K*)q; q += align_up(n * sizeof(K)); tv[i] = (uint32_t*)q; q += align_up(n * sizeof(uint32_t)); }
     // the table is written in full by os_tile_hist_kernel: only the words in front of it need clearing
-    hipError_t e = hipMemsetAsync(base, 0, pre0 ? (size_t)((char*)table - base) : ctrl, s);
-    if (e != hipSuccess) return e;
+    if (!ctrl_cleared) {
+        const hipError_t e = hipMemsetAsync(base, 0, os_clear_bytes<K>(n, total_bits), s);
+        if (e != hipSuccess) return e;
+    }
     if constexpr (pre0) {
         os_tile_hist_kernel<<<(unsigned)blocks, 1024, 0, s>>>((const uint16_t*)kin, (uint32_t)n, plan, table);
         os_table_scan_kernel<<<(unsigned)((1 << plan.bits[0]) + (plan.passes > 1 ? (1 << plan.bits[1]) : 0)), 256, 0, s>>>(table, (uint32_t)blocks, plan, hist);
@@ -474,20 +489,25 @@ size_t onesweep_tile_temp_bytes(int R, int end_bit, int key_bytes)
 {
     return key_bytes == 4 ? os_temp_bytes<uint32_t>((size_t)(R > 0 ? R : 1), end_bit) : os_temp_bytes<uint16_t>((size_t)(R > 0 ? R : 1), end_bit);
 }
-hipError_t onesweep_tile_sort32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
-                                int R, int end_bit, hipStream_t s)
+size_t onesweep_depth_clear_bytes(int P) { return os_clear_bytes<uint32_t>((size_t)(P > 0 ? P : 1), 32); }
+size_t onesweep_tile_clear_bytes(int R, int end_bit, int key_bytes)
 {
-    return os_sort<uint32_t>(temp, temp_bytes, kin, kout, vin, vout, (size_t)R, end_bit, s);
+    return key_bytes == 4 ? os_clear_bytes<uint32_t>((size_t)(R > 0 ? R : 1), end_bit) : os_clear_bytes<uint16_t>((size_t)(R > 0 ? R : 1), end_bit);
+}
+hipError_t onesweep_tile_sort32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                                int R, int end_bit, hipStream_t s, bool ctrl_cleared)
+{
+    return os_sort<uint32_t>(temp, temp_bytes, kin, kout, vin, vout, (size_t)R, end_bit, s, nullptr, nullptr, ctrl_cleared);
 }
 hipError_t onesweep_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
-                               int P, const uint2* gather_src, uint2* gather_dst, hipStream_t s)
+                               int P, const uint2* gather_src, uint2* gather_dst, hipStream_t s, bool ctrl_cleared)
 {
-    return os_sort<uint32_t>(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 32, s, gather_src, gather_dst);
+    return os_sort<uint32_t>(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 32, s, gather_src, gather_dst, ctrl_cleared);
 }
 hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin, uint32_t* vout,
-                              int R, int end_bit, hipStream_t s)
+                              int R, int end_bit, hipStream_t s, bool ctrl_cleared)
 {
-    return os_sort<uint16_t>(temp, temp_bytes, kin, kout, vin, vout, (size_t)R, end_bit, s);
+    return os_sort<uint16_t>(temp, temp_bytes, kin, kout, vin, vout, (size_t)R, end_bit, s, nullptr, nullptr, ctrl_cleared);
 }
 
 } // namespace c3dgs

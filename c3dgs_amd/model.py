@@ -249,6 +249,10 @@ class _QatGetters(torch.autograd.Function):
                                                                        "rotation", "fdc", "frest")])
         outs = (means3D, means2D, opac, sfac, scales_n, rotations, shs, sh_out, g_out)
         ctx.mark_non_differentiable(*[t for t in (sh_out, g_out) if t is not None and vis is not None])
+        # without this, autograd hands backward zero-filled int64[V] "gradients" for the two index outputs on every call
+        # (2 x 24 MB of fills at V = 3M); a differentiable output nobody used arrives as None and is filled below
+        ctx.set_materialize_grads(False)
+        ctx.V = V
         return outs
 
     @staticmethod
@@ -268,6 +272,14 @@ class _QatGetters(torch.autograd.Function):
         c = lambda t: None if t is None else t.contiguous()
         g_m3, g_m2, g_op, g_sf, g_scales, g_rot, g_shs = map(c, (g_m3, g_m2, g_op, g_sf, g_scales, g_rot, g_shs))
         P = ctx.P
+        if g_m3 is None and xyz is not None and need[4]:
+            g_m3 = torch.zeros(ctx.V, 3, **f32)
+        if g_m2 is None and ctx.has_screen and need[5]:
+            g_m2 = torch.zeros(ctx.V, 3, **f32)
+        if g_op is None and opacity is not None and need[6]:
+            g_op = torch.zeros(ctx.V, 1, **f32)
+        if g_sf is None and sfac is not None and need[7]:
+            g_sf = torch.zeros(ctx.V, 1, **f32)
         d_xyz = torch.empty(P, 3, **f32) if (xyz is not None and need[4]) else None
         d_screen = torch.empty(P, 3, **f32) if (ctx.has_screen and need[5]) else None
         d_op = torch.empty(P, 1, **f32) if (opacity is not None and need[6]) else None

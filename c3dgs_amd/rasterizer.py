@@ -438,11 +438,30 @@ def _c_mark_visible(means3D, viewmatrix, projmatrix):
         raise RuntimeError("c3dgs_amd: means3D must be a GPU tensor (there is no CPU path)")
     m = _f32c(means3D, "means3D")
     P = int(means3D.size(0))
-    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    present = torch.empty((P,), dtype=torch.bool, device=means3D.device)     # the kernel writes every element
     if P != 0:
         v, pr = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix")
         with torch.cuda.device(means3D.device):
             rc = L.c3dgs_mark_visible(P, m.data_ptr(), v.data_ptr(), pr.data_ptr(), present.data_ptr(), _stream(means3D.device))
+        _lib.check(rc)
+    return present
+
+
+def _mark_visible_from_pose(positions, extrinsic_vector):
+    """markVisible for a 7-element pose on the GPU in ONE launch (c3dgs_mark_visible_pose: same flags, bit for bit, as
+    camera_matrices + _C.mark_visible, without the single-thread matrix kernel in front). None: not that case."""
+    if not positions.is_cuda or extrinsic_vector.dim() != 1 or extrinsic_vector.numel() != 7:
+        return None
+    dev = positions.device
+    pose = extrinsic_vector.detach()
+    if pose.device != dev or pose.dtype != torch.float32 or not pose.is_contiguous():
+        pose = pose.to(device=dev, dtype=torch.float32).contiguous()
+    m = _f32c(positions, "means3D")
+    P = int(positions.size(0))
+    present = torch.empty((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        with torch.cuda.device(dev):
+            rc = _lib.lib().c3dgs_mark_visible_pose(P, m.data_ptr(), pose.data_ptr(), present.data_ptr(), _stream(dev))
         _lib.check(rc)
     return present
 
@@ -492,7 +511,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.camera = (view, proj, campos, tanfovx, tanfovy)
         ctx.save_for_backward(extrinsic_vector, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer)
+        ctx.image_shape = tuple(color.shape)
         ctx.mark_non_differentiable(radii)
+        # without this, autograd hands backward a zero-filled int32[P] "gradient" for radii on every call (a 12 MB fill at P = 3M)
+        ctx.set_materialize_grads(False)
         return color, radii
 
     @staticmethod
@@ -500,6 +522,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (extrinsic_vector, colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
+        grad_out_color = _dense_grad(grad_out_color, ctx)
         view, proj, campos, tanfovx, tanfovy = ctx.camera
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, view, proj,
                 tanfovx, tanfovy, grad_out_color, sh, rs.sh_degree, campos, geomBuffer, ctx.num_rendered, binningBuffer,
@@ -543,11 +566,22 @@ def _indexed_forward(ctx, means3D, sh, sh_indices, g_indices, colors_precomp, op
     ctx.save_for_backward(extrinsic_vector, colors_precomp, means3D, scales, scale_factors, rotations, cov3Ds_precomp, radii,
                           sh, geomBuffer, binningBuffer, imgBuffer, sh_indices, g_indices)
     ctx.mark_non_differentiable(radii)
+    ctx.set_materialize_grads(False)       # no zero-filled int32[P] "gradient" for radii (see _RasterizeGaussians.forward)
+    ctx.image_shape = tuple(color.shape)
     return color, radii
+
+
+def _dense_grad(grad_out_color, ctx):
+    """set_materialize_grads(False): an image nobody differentiated through arrives as None (backward still runs when only
+    `radii` was used downstream of a graph that needs grad); the library wants a dense dL/dC."""
+    if grad_out_color is not None:
+        return grad_out_color
+    return torch.zeros(ctx.image_shape, dtype=torch.float32, device=ctx.saved_tensors[2].device)
 
 
 def _indexed_backward(ctx, grad_out_color):
     rs = ctx.raster_settings
+    grad_out_color = _dense_grad(grad_out_color, ctx)
     (extrinsic_vector, colors_precomp, means3D, scales, scale_factors, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
      binningBuffer, imgBuffer, sh_indices, g_indices) = ctx.saved_tensors
     view, proj, campos, tanfovx, tanfovy = ctx.camera
@@ -710,6 +744,9 @@ class GaussianRasterizer(nn.Module):
 
     def markVisible(self, positions, extrinsic_vector):
         with torch.no_grad():
+            present = _mark_visible_from_pose(positions, extrinsic_vector)
+            if present is not None:
+                return present
             view, proj = camera_matrices(self.raster_settings.intrinsic, extrinsic_vector, positions.device)[:2]
             return _C.mark_visible(positions, view, proj)
 
@@ -737,6 +774,9 @@ class GaussianRasterizerIndexed(nn.Module):
 
     def markVisible(self, positions, extrinsic_vector):
         with torch.no_grad():
+            present = _mark_visible_from_pose(positions, extrinsic_vector)
+            if present is not None:
+                return present
             view, proj = camera_matrices(self.raster_settings.intrinsic, extrinsic_vector, positions.device)[:2]
             return _C.mark_visible(positions, view, proj)
 

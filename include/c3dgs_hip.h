@@ -97,6 +97,11 @@ int c3dgs_camera_from_pose(const float* extrinsic_vector, float inv_tan_half_fov
 /* ---- _C.mark_visible (rasterize_points.cu:202-221 -> rasterizer_impl.cu:54-66,141-149) ---- */
 int c3dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                        uint8_t* present /*[P] bool*/, void* stream);
+/* The same test from the camera's POSE (device pointer to qx, qy, qz, qw, tx, ty, tz: what GaussianRasterizer*.markVisible is
+ * handed, DGR-NC __init__.py:937-949): the matrix entries the test reads are formed per thread with the fp32 operations of
+ * c3dgs_camera_from_pose, so the flags equal c3dgs_camera_from_pose + c3dgs_mark_visible bit for bit, in one launch. */
+int c3dgs_mark_visible_pose(int32_t P, const float* means3D, const float* extrinsic_vector, uint8_t* present /*[P] bool*/,
+                            void* stream);
 
 /* ---- _C.rasterize_gaussians (rasterize_points.cu:35-117 -> rasterizer_impl.cu:194-334) ----
  * p->sh_indices, p->g_indices, p->scale_factors must be NULL.

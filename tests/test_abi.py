@@ -58,6 +58,8 @@ def test_validation_without_gpu(L):
     assert b"dimension 2" in L.c3dgs_last_error()
     assert L.c3dgs_mark_visible(0, None, None, None, None, None) == 0
     assert L.c3dgs_mark_visible(5, None, None, None, None, None) == 1
+    assert L.c3dgs_mark_visible_pose(0, None, None, None, None) == 0
+    assert L.c3dgs_mark_visible_pose(5, None, None, None, None) == 1
     p = _lib.RasterParams()
     p.P, p.W, p.H = 4, 64, 64
     n = C.c_int32(0)

@@ -112,6 +112,52 @@ def test_mark_visible(hip, orc):
     assert 0 < ref.sum() < ref.size
 
 
+def test_mark_visible_from_the_pose_equals_the_matrix_path(hip, orc):
+    """GaussianRasterizer*.markVisible with a 7-element pose takes c3dgs_mark_visible_pose (one launch: the matrix entries the
+    test reads are formed per thread). Its flags must equal camera_from_pose + mark_visible bit for bit -- checked on points
+    spread THROUGH the z = 0.01 plane of a camera with an un-normalised quaternion, where one ulp of a matrix entry flips flags."""
+    import c3dgs_amd
+    from c3dgs_amd import rasterizer as rz
+    g = torch.Generator().manual_seed(5)
+    intr, _ = synth.camera(320, 200, 200.0)
+    for trial in range(4):
+        q = torch.randn(4, generator=g) * (1.0 if trial else 0.3)            # not normalised (the reference does not either)
+        t = torch.randn(3, generator=g)
+        ev = torch.cat([q, t]).float()
+        cam = orc.camera(intr.numpy(), ev.numpy())
+        W2C = torch.from_numpy(cam["viewmatrix"]).T.double()                   # viewmatrix is stored transposed
+        n = 200_003
+        pts_cam = torch.randn(n, 3, generator=g).double()
+        pts_cam[:, 2] = 0.01 + (torch.rand(n, generator=g).double() - 0.5) * torch.logspace(-7, 0, n).double()
+        Rm, tv = W2C[:3, :3], W2C[:3, 3]
+        pts = (torch.linalg.solve(Rm, (pts_cam - tv).T).T).float().cuda()
+        rs = c3dgs_amd.GaussianRasterizationSettings(intrinsic=intr, extrinsic_vector=ev.cuda(), bg=torch.zeros(3).cuda(), scale_modifier=1.0,
+                                                     sh_degree=0, prefiltered=False, debug=False, clamp_color=True)
+        got = c3dgs_amd.GaussianRasterizerIndexed(rs).markVisible(pts, extrinsic_vector=ev.cuda())
+        assert rz._mark_visible_from_pose(pts, ev.cuda()) is not None
+        view, proj = rz.camera_matrices(intr, ev.cuda(), pts.device)[:2]
+        ref = rz._C.mark_visible(pts, view, proj)
+        assert torch.equal(got, ref)
+        assert 0.2 < float(ref.float().mean()) < 0.8
+        np.testing.assert_array_equal(got.cpu().numpy(), orc.mark_visible(pts.cpu().numpy(), view.cpu().numpy(), proj.cpu().numpy()))
+
+
+def test_forward_with_the_copy_based_host_read(hip):
+    """The forward's one device->host read normally arrives through MAPPED host memory the scan kernel stores into;
+    C3DGS_HOST_READ_COPY=1 forces the hipMemcpyAsync + event path (what a host that cannot map the pad falls back to). The
+    parity cases must pass unchanged with it. Child process: the switch is read once per thread."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, C3DGS_HOST_READ_COPY="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_raster_gpu.py", "-q", "-m", "gpu", "-x",
+                        "-k", "forward_parity and (base or p8193 or empty or all_behind or indexed)"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_full_hd_properties(hip):
     """BASELINE.json full size (1920x1080, 1M Gaussians) through size-independent properties:
     sorted keys are non-decreasing, the sorted list is a permutation of the unsorted one, ranges partition
