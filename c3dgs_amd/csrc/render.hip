@@ -35,7 +35,8 @@ constexpr int BATCH = 256;
 __device__ unsigned long long g_lane_counters[16];
 
 #ifndef C3DGS_BWD_ABLATE
-#define C3DGS_BWD_ABLATE 0      // timing-only experiment builds: bit 0 = no partial-sum stores, bit 1 = cache-resident record gathers
+#define C3DGS_BWD_ABLATE 0      // timing-only experiment builds (WRONG gradients): bit 0 = no partial-sum stores, bit 1 = cache-resident
+                                // record gathers, bit 2 = without the two in-bank reduction levels, bit 3 = without any reduction
 #endif
 #ifdef C3DGS_BWD_TIMING
 // phase clocks of render_backward (experiment build variant "bwdtime"): shader-clock ticks summed over all waves:
@@ -670,14 +671,21 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
                 // which leaves the register allocator room (96 registers = five waves per SIMD) to request the NEXT Gaussian's
                 // record from LDS while this one is blended; with all 48 live every record read sat directly in front of its
                 // first use (three LDS latencies per Gaussian and wave, exposed).
+#if C3DGS_BWD_ABLATE & 8      // timing-only build: no reduction at all (the six values are merely kept alive)
+#pragma unroll
+                for (int q = 0; q < NCOL; q++) asm volatile("" : : "v"(v[g * NCOL + q]));
+#else
                 if (g == 4) { C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, 0, 24); }
                 if (g == 5) { C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, 4, 24); C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, 8, 24); }
                 if (g == 6) { C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, 12, 24); }
                 if (g == 7) { C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, 16, 24); C3DGS_TR4("row_half_mirror", "0x5", "0xa", u, v, v, 20, 24); }
+#endif
             }
             row0 = *reinterpret_cast<const uint4*>(lrow + GROUP_G);          // next group's row (in bounds: the list is padded)
             row1 = *reinterpret_cast<const uint4*>(lrow + GROUP_G + 4);
+#if !(C3DGS_BWD_ABLATE & 12)  // timing-only builds: bit 2 = without the two in-bank column levels, bit 3 = without any reduction
             reduce_columns_24(u, lane);
+#endif
             a_n = *reinterpret_cast<const float4*>(rec_base + row0.x);          // ... and its first record, behind the row levels
             b_n = *reinterpret_cast<const float4*>(rec_base + row0.x + 16);
             c_n = *reinterpret_cast<const float*>(blue_base + (row0.x >> 3));
@@ -686,9 +694,15 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             const int myj = (int)(my_off >> 5);                  // offset / 32
             const float dyb = *reinterpret_cast<const float*>(rec_base + my_off + 4) - pyf;
             // row sums {c0, c1, c2, S0, Sx, Sxx} of Gaussian slot beta -> the nine terms {.., Sy, Sxy | Syy}
-            const float nine[NPART] = { u[0], u[1], u[2], u[3], u[4], u[5], dyb * u[3], dyb * u[4], (dyb * dyb) * u[3] };
             float total, ninth;
+#if !(C3DGS_BWD_ABLATE & 8)
+            const float nine[NPART] = { u[0], u[1], u[2], u[3], u[4], u[5], dyb * u[3], dyb * u[4], (dyb * dyb) * u[3] };
+#endif
+#if C3DGS_BWD_ABLATE & 8
+            total = v[0]; ninth = dyb;
+#else
             reduce_rows_9(nine, total, ninth);
+#endif
             // LDS float add into the plane this wave shares with ONE other wave: every (entry, term) receives at most
             // one add per wave, and a + b == b + a, so the result does not depend on which wave arrives first
             if (myj < BATCH) {
