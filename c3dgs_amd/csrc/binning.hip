@@ -67,10 +67,11 @@ size_t tile_sort_clear_bytes(int R, int end_bit, int key_bytes)
 }
 
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
-                          uint32_t* vout, int P, const uint2* rects, uint2* rects_sorted, hipStream_t s, bool ctrl_cleared)
+                          uint32_t* vout, int P, const uint2* rects, uint2* rects_sorted, hipStream_t s, bool ctrl_cleared,
+                          bool rects_fit_bytes)
 {
     if (onesweep_enabled() && (size_t)P < ((size_t)1 << 30))
-        return onesweep_depth_sort(temp, temp_bytes, kin, kout, vin, vout, P, rects, rects_sorted, s, ctrl_cleared);
+        return onesweep_depth_sort(temp, temp_bytes, kin, kout, vin, vout, P, rects, rects_sorted, s, ctrl_cleared, rects_fit_bytes);
     // vin == nullptr: the payload is the Gaussian id itself (0 .. P-1)
     hipError_t e = vin ? rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 0u, 32u, s)
                        : rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, rocprim::counting_iterator<uint32_t>(0u), vout,

@@ -174,7 +174,8 @@ static int forward_impl(const c3dgs_raster_params* pp, bool indexed, c3dgs_resiz
     }
     { StageTimer t_(ST_DEPTH_SORT, s);                                               // binning stage 1: P Gaussians by depth
       C3DGS_HIP_TRY(run_depth_sort(g.scan_temp, g.scan_temp_bytes, g.depth_keys, g.depth_keys_sorted, nullptr, g.depth_order, P,
-                                   reinterpret_cast<const uint2*>(g.rects), g.sorted_offsets, s, dclear != 0)); }
+                                   reinterpret_cast<const uint2*>(g.rects), g.sorted_offsets, s, dclear != 0,
+                                   /*rects_fit_bytes=*/gx <= 255 && gy <= 255)); }
     C3DGS_STAGE("depth_sort", p.debug, s);
     if (p.debug && onesweep_timed_out(s)) return fail(C3DGS_E_HIP, "depth sort: look-back timed out");
     { StageTimer t_(ST_SCAN, s); launch_depth_order_scan(P, g, s); }                 // K3, in depth order (two-level)

@@ -165,8 +165,10 @@ void launch_identify_ranges(int R, const void* keys_sorted, int key_bytes, uint2
 // binning.hip
 // ctrl_cleared: the first *_sort_clear_bytes(...) bytes of `temp` were zeroed by an earlier kernel on the same stream
 // (0 bytes = this configuration's sort clears its own control words: pass false)
+// rects_fit_bytes: all rectangle coordinates < 256 (at most 255 x 255 tiles): the rectangles may ride through the sort packed
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
-                          uint32_t* vout, int P, const uint2* rects, uint2* rects_sorted, hipStream_t s, bool ctrl_cleared = false);
+                          uint32_t* vout, int P, const uint2* rects, uint2* rects_sorted, hipStream_t s, bool ctrl_cleared = false,
+                          bool rects_fit_bytes = false);
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, const void* kin, void* kout, int key_bytes, const uint32_t* vin,
                          uint32_t* vout, int R, int end_bit, hipStream_t s, bool ctrl_cleared = false);
 size_t depth_sort_clear_bytes(int P);
@@ -180,7 +182,8 @@ size_t onesweep_tile_temp_bytes(int R, int end_bit, int key_bytes = 2);
 size_t onesweep_depth_clear_bytes(int P);
 size_t onesweep_tile_clear_bytes(int R, int end_bit, int key_bytes);
 hipError_t onesweep_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
-                               int P, const uint2* gather_src, uint2* gather_dst, hipStream_t s, bool ctrl_cleared = false);
+                               int P, const uint2* gather_src, uint2* gather_dst, hipStream_t s, bool ctrl_cleared = false,
+                               bool rects_fit_bytes = false);
 hipError_t onesweep_tile_sort32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
                                 int R, int end_bit, hipStream_t s, bool ctrl_cleared = false);   // 32-bit tile keys (more than 65,536 tiles)
 hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin, uint32_t* vout,

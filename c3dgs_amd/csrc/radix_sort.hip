@@ -197,11 +197,26 @@ __device__ __forceinline__ void os_store(uint32_t* p, uint32_t v) { __hip_atomic
 
 // PRE: the tile's exclusive digit prefixes come from the table os_table_scan_kernel prepared (`status` = the table, no ticket,
 // no look-back); otherwise they are found by the chained look-back over the earlier tiles' status words.
-template <class K, int BITS, bool PRE>
+// PAY2 (depth sort): a SECOND 32-bit payload travels with every item -- the Gaussian's tile rectangle packed to four bytes
+// (os_pack_rect: grids up to 255 x 255 tiles). The first pass reads the rectangles coalesced, in id order, from `gather_src`
+// (p2in == null); the passes hand the packed word on through p2in / p2out; the last pass (p2out == null) unpacks it into
+// gather_dst in sorted order. Without it the last pass GATHERS gather_src[id]: 3M random 8-byte reads = 3M x 128-byte lines,
+// 42 us at the fabric's line rate for P = 3M (tools/step_timeline.py) against ~4 us more per pass for the extra payload.
+__device__ __forceinline__ uint32_t os_pack_rect(uint2 r)
+{
+    return (r.x & 0xffu) | ((r.x >> 16) << 8) | ((r.y & 0xffu) << 16) | ((r.y >> 16) << 24);
+}
+__device__ __forceinline__ uint2 os_unpack_rect(uint32_t w)
+{
+    return make_uint2((w & 0xffu) | (((w >> 8) & 0xffu) << 16), ((w >> 16) & 0xffu) | ((w >> 24) << 16));
+}
+
+template <class K, int BITS, bool PRE, bool PAY2 = false>
 __global__ void __launch_bounds__(OsShape<K>::BLOCK)
 os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout,
                uint32_t n, int shift, const uint32_t* __restrict__ hist, uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
-               const uint2* __restrict__ gather_src, uint2* __restrict__ gather_dst)
+               const uint2* __restrict__ gather_src, uint2* __restrict__ gather_dst, const uint32_t* __restrict__ p2in = nullptr,
+               uint32_t* __restrict__ p2out = nullptr)
 {
     constexpr uint32_t ERR_BIT = sizeof(K) == 2 ? 1u : 2u;
     constexpr uint32_t MASK = (1u << BITS) - 1;
@@ -214,6 +229,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
     constexpr int OS_TILE = OsShape<K>::TILE;
     __shared__ K s_keys[OS_TILE];
     __shared__ uint32_t s_vals[OS_TILE];
+    __shared__ uint32_t s_vals2[PAY2 ? OS_TILE : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_bid = PRE ? blockIdx.x : atomicAdd(ticket, 1u);
@@ -226,6 +242,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
 
     K key[OS_IPT];
     uint32_t val[OS_IPT], rank[OS_IPT];
+    uint32_t val2[PAY2 ? OS_IPT : 1];
     const uint32_t wbase = block_start + (uint32_t)wave * 64u * OS_IPT;
 #pragma unroll
     for (int k = 0; k < OS_IPT; k++) {
@@ -233,6 +250,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
         const bool ok = idx < n;
         key[k] = ok ? kin[idx] : (K)0;
         val[k] = ok ? (vin ? vin[idx] : idx) : 0u;             // no payload array: the payload is the item's index
+        if (PAY2) val2[k] = ok ? (p2in ? p2in[idx] : os_pack_rect(gather_src[idx])) : 0u;
     }
     // ranking: lanes with the same digit find each other with BITS ballots. Written on 32-bit halves with the digit bit as a
     // 0 / -1 mask so that a bit costs six vector instructions (v_bfe_i32, v_cmp, 2 x v_xnor, 2 x v_and); the obvious
@@ -332,6 +350,7 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
             const uint32_t p = s_start[d] + s_cnt[wave][d] + rank[k];
             s_keys[p] = key[k];
             s_vals[p] = val[k];
+            if (PAY2) s_vals2[p] = val2[k];
         }
     }
     __syncthreads();
@@ -346,7 +365,10 @@ os_pass_kernel(const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* 
             kout[g] = kk;
             const uint32_t vv = s_vals[p];
             vout[g] = vv;
-            if (gather_src) gather_dst[g] = gather_src[vv];     // last pass of the depth sort: per-Gaussian data in sorted order
+            if (PAY2) {
+                if (p2out) p2out[g] = s_vals2[p];
+                else gather_dst[g] = os_unpack_rect(s_vals2[p]);   // last pass: the rectangles arrive with their items
+            } else if (gather_src) gather_dst[g] = gather_src[vv]; // last pass of the depth sort: per-Gaussian data in sorted order
         }
     }
 #ifdef C3DGS_OS_TIMING
@@ -370,12 +392,13 @@ static void os_launch_pass(int bits, unsigned blocks, hipStream_t s, const K* ki
 
 // temp = [control block | ping buffer (keys, values) | pong buffer]; the input arrays are never written
 template <class K>
-static size_t os_temp_bytes(size_t n, int total_bits)
+static size_t os_temp_bytes(size_t n, int total_bits, bool pay2 = false)
 {
     const OsPlan plan = os_plan(total_bits);
     size_t b = os_ctrl_bytes<K>(n, plan.passes);
     const int bufs = plan.passes >= 3 ? 2 : (plan.passes == 2 ? 1 : 0);
     b += (size_t)bufs * (align_up(n * sizeof(K)) + align_up(n * sizeof(uint32_t)));
+    if (pay2) b += 2 * align_up(n * sizeof(uint32_t));       // ping-pong of the second payload, behind everything else
     return b;
 }
 
@@ -394,9 +417,13 @@ static size_t os_clear_bytes(size_t n, int total_bits)
 template <class K>
 static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, size_t n,
                           int total_bits, hipStream_t s, const uint2* gather_src = nullptr, uint2* gather_dst = nullptr,
-                          bool ctrl_cleared = false)
+                          bool ctrl_cleared = false, bool pay2 = false)
 {
     if (n == 0) return hipSuccess;
+    // second payload (see os_pass_kernel): u32 keys in four 8-bit passes with a rectangle table only, and only if the caller's
+    // scratch has room for its two buffers
+    if (pay2 && (sizeof(K) != 4 || total_bits != 32 || !gather_src || !gather_dst || vin || os_temp_bytes<K>(n, total_bits, true) > temp_bytes))
+        pay2 = false;
     if (n >= ((size_t)1 << 30) || os_temp_bytes<K>(n, total_bits) > temp_bytes) return hipErrorInvalidValue;
     const OsPlan plan = os_plan(total_bits);
     const size_t blocks = os_blocks<K>(n);
@@ -410,6 +437,11 @@ static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, 
     K* tk[2]; uint32_t* tv[2];
     char* q = base + ctrl;
     for (int i = 0; i < 2; i++) { tk[i] = (K*)q; q += align_up(n * sizeof(K)); tv[i] = (uint32_t*)q; q += align_up(n * sizeof(uint32_t)); }
+    uint32_t* t2[2] = { nullptr, nullptr };
+    if (pay2) {
+        q = base + os_temp_bytes<K>(n, total_bits);
+        for (int i = 0; i < 2; i++) { t2[i] = (uint32_t*)q; q += align_up(n * sizeof(uint32_t)); }
+    }
     // the table is written in full by os_tile_hist_kernel: only the words in front of it need clearing
     if (!ctrl_cleared) {
         const hipError_t e = hipMemsetAsync(base, 0, os_clear_bytes<K>(n, total_bits), s);
@@ -433,6 +465,15 @@ static hipError_t os_sort(void* temp, size_t temp_bytes, const K* kin, K* kout, 
         uint32_t* vo = p == plan.passes - 1 ? vout : tv[p & 1];
         const bool last = p == plan.passes - 1;
         // ticket + p is this pass's counter
+        if constexpr (sizeof(K) == 4) {
+            if (pay2) {
+                os_pass_kernel<K, 8, false, true><<<(unsigned)blocks, OsShape<K>::BLOCK, 0, s>>>(
+                    ki, ko, vi, vo, (uint32_t)n, shift, hist + (size_t)p * OS_RADIX, status + (size_t)p * blocks * OS_RADIX, ticket + p,
+                    gather_src, gather_dst, p == 0 ? nullptr : t2[(p - 1) & 1], last ? nullptr : t2[p & 1]);
+                shift += plan.bits[p];
+                continue;
+            }
+        }
         if (pre0 && p == 0)
             os_launch_pass<K, true>(plan.bits[p], (unsigned)blocks, s, ki, ko, vi, vo, (uint32_t)n, shift, hist, table, ticket,
                                     last ? gather_src : nullptr, last ? gather_dst : nullptr);
@@ -484,7 +525,7 @@ bool onesweep_enabled()
     static const bool on = []() { const char* e = std::getenv("C3DGS_SORT_ROCPRIM"); return !(e && e[0] == '1'); }();
     return on;
 }
-size_t onesweep_depth_temp_bytes(int P) { return os_temp_bytes<uint32_t>((size_t)(P > 0 ? P : 1), 32); }
+size_t onesweep_depth_temp_bytes(int P) { return os_temp_bytes<uint32_t>((size_t)(P > 0 ? P : 1), 32, true); }   // room for the second payload
 size_t onesweep_tile_temp_bytes(int R, int end_bit, int key_bytes)
 {
     return key_bytes == 4 ? os_temp_bytes<uint32_t>((size_t)(R > 0 ? R : 1), end_bit) : os_temp_bytes<uint16_t>((size_t)(R > 0 ? R : 1), end_bit);
@@ -500,9 +541,13 @@ hipError_t onesweep_tile_sort32(void* temp, size_t temp_bytes, const uint32_t* k
     return os_sort<uint32_t>(temp, temp_bytes, kin, kout, vin, vout, (size_t)R, end_bit, s, nullptr, nullptr, ctrl_cleared);
 }
 hipError_t onesweep_depth_sort(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
-                               int P, const uint2* gather_src, uint2* gather_dst, hipStream_t s, bool ctrl_cleared)
+                               int P, const uint2* gather_src, uint2* gather_dst, hipStream_t s, bool ctrl_cleared, bool rects_fit_bytes)
 {
-    return os_sort<uint32_t>(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 32, s, gather_src, gather_dst, ctrl_cleared);
+    // rects_fit_bytes: every coordinate of the tile rectangles is below 256 (grid of at most 255 x 255 tiles), so they can
+    // travel with the items as a packed 32-bit second payload instead of being gathered behind the last pass
+    static const bool no_pay2 = []() { const char* e = std::getenv("C3DGS_DEPTH_SORT_GATHER"); return e && e[0] == '1'; }();
+    return os_sort<uint32_t>(temp, temp_bytes, kin, kout, vin, vout, (size_t)P, 32, s, gather_src, gather_dst, ctrl_cleared,
+                             rects_fit_bytes && !no_pay2);
 }
 hipError_t onesweep_tile_sort(void* temp, size_t temp_bytes, const uint16_t* kin, uint16_t* kout, const uint32_t* vin, uint32_t* vout,
                               int R, int end_bit, hipStream_t s, bool ctrl_cleared)
