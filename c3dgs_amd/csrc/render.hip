@@ -36,7 +36,8 @@ __device__ unsigned long long g_lane_counters[16];
 
 #ifndef C3DGS_BWD_ABLATE
 #define C3DGS_BWD_ABLATE 0      // timing-only experiment builds (WRONG gradients): bit 0 = no partial-sum stores, bit 1 = cache-resident
-                                // record gathers, bit 2 = without the two in-bank reduction levels, bit 3 = without any reduction
+                                // record gathers, bit 2 = without the two in-bank reduction levels, bit 3 = without any reduction, bit 4 = records read
+                                // coalesced by list position (what parking the forward's staged records would give)
 #endif
 #ifdef C3DGS_BWD_TIMING
 // phase clocks of render_backward (experiment build variant "bwdtime"): shader-clock ticks summed over all waves:
@@ -544,7 +545,9 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             // the entry's Gaussian id and quadrant mask were requested one round ago (below): the record gather is the only
             // memory round trip left in front of this round's blending (measured with the "bwdtime" variant: the dependent chain
             // point list -> record was 31 % of a wave's lifetime, more than its group loop)
-#if C3DGS_BWD_ABLATE & 2
+#if C3DGS_BWD_ABLATE & 16
+            const uint32_t id = (range.x + (uint32_t)mypos) & 0x1fffffu;   // timing-only build: coalesced records, no dependence on the point list
+#elif C3DGS_BWD_ABLATE & 2
             const uint32_t id = next_id & 4095u;                  // timing-only build: records from a cache-resident corner of the array
 #else
             const uint32_t id = next_id;
@@ -555,7 +558,7 @@ render_backward_kernel(int W, int H, int gx, int T, const uint2* __restrict__ ra
             prescale_conic(a, b);
             const uint32_t off = __float_as_uint(c.y), lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
             const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
-#if C3DGS_BWD_ABLATE & 2
+#if C3DGS_BWD_ABLATE & 18
             s_slot[tid] = range.x + (uint32_t)mypos;              // timing-only build: a slot that exists (the record is not this entry's)
             (void)off; (void)x0; (void)y0; (void)x1;
 #else
