@@ -104,59 +104,29 @@ __global__ void __launch_bounds__(OS_HIST_BLOCK) os_hist_kernel(const K* __restr
     constexpr int VEC = 16 / sizeof(K);                     // keys per 16-byte load
     const size_t nvec = n / VEC;
     const uint4* k4 = reinterpret_cast<const uint4*>(keys);
-    // The TOP digit of depth keys takes two or three values (one exponent band or two, plus the culled Gaussians' 0xffffffff), so
-    // its 64 LDS atomics of a wave hit two or three words and serialise. It is counted per wave instead: up to four rounds of
-    // "first active lane's value -> ballot of the lanes that share it -> one add of their number"; lanes still left after that
-    // (a high-entropy top digit) fall back to their own atomic. Called by all lanes of a wave together (the callers' loops are
-    // wave-uniform; lanes without a key pass ok = false).
-    const int top = plan.passes - 1;
-    int top_shift = 0;
-    for (int p = 0; p < top; p++) top_shift += plan.bits[p];
-    const uint32_t top_mask = (1u << plan.bits[top]) - 1u;
-    auto add_top = [&](uint32_t k, bool ok) {
-        const uint32_t d = (k >> top_shift) & top_mask;
-        unsigned long long left = __ballot(ok);
-#pragma unroll 1
-        for (int it = 0; it < 4 && left; it++) {
-            const int leader = __ffsll((long long)left) - 1;
-            const uint32_t dl = (uint32_t)__shfl((int)d, leader);
-            const unsigned long long same = __ballot(ok && d == dl) & left;
-            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&s_h[top][dl], (uint32_t)__popcll(same));
-            left &= ~same;
-        }
-        if ((left >> (threadIdx.x & 63)) & 1ull) atomicAdd(&s_h[top][d], 1u);
-    };
-    auto add = [&](uint32_t k, bool ok) {
+    auto add = [&](uint32_t k) {
         int shift = 0;
-        for (int p = 0; p < top; p++) {
-            if (ok) atomicAdd(&s_h[p][(k >> shift) & ((1u << plan.bits[p]) - 1u)], 1u);
+        for (int p = 0; p < plan.passes; p++) {
+            atomicAdd(&s_h[p][(k >> shift) & ((1u << plan.bits[p]) - 1u)], 1u);
             shift += plan.bits[p];
         }
-        add_top(k, ok);
     };
-    auto add4 = [&](const uint4 v, bool ok) {
+    auto add4 = [&](const uint4 v) {
         const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            if (sizeof(K) == 4) add(w[e], ok);
-            else { add(w[e] & 0xffffu, ok); add(w[e] >> 16, ok); }
+            if (sizeof(K) == 4) add(w[e]);
+            else { add(w[e] & 0xffffu); add(w[e] >> 16); }
         }
     };
     const size_t stride = (size_t)gridDim.x * OS_HIST_BLOCK;
-    const size_t i0 = (size_t)blockIdx.x * OS_HIST_BLOCK + threadIdx.x, w0 = i0 - (threadIdx.x & 63);   // w0: the wave's first item
-    size_t i = i0, iw = w0;
-    for (; iw + 3 * stride + 63 < nvec; i += 4 * stride, iw += 4 * stride) {                              // the whole wave is in range
+    size_t i = (size_t)blockIdx.x * OS_HIST_BLOCK + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
         const uint4 v0 = k4[i], v1 = k4[i + stride], v2 = k4[i + 2 * stride], v3 = k4[i + 3 * stride];
-        add4(v0, true); add4(v1, true); add4(v2, true); add4(v3, true);
+        add4(v0); add4(v1); add4(v2); add4(v3);
     }
-    for (; iw < nvec; i += stride, iw += stride) {                                                          // wave-uniform trip count
-        const bool ok = i < nvec;
-        add4(ok ? k4[i] : make_uint4(0u, 0u, 0u, 0u), ok);
-    }
-    {
-        size_t j = nvec * VEC + i0, jw = nvec * VEC + w0;
-        for (; jw < n; j += stride, jw += stride) { const bool ok = j < n; add(ok ? (uint32_t)keys[j] : 0u, ok); }
-    }
+    for (; i < nvec; i += stride) add4(k4[i]);
+    for (size_t j = nvec * VEC + (size_t)blockIdx.x * OS_HIST_BLOCK + threadIdx.x; j < n; j += stride) add((uint32_t)keys[j]);
     __syncthreads();
     for (int q = threadIdx.x; q < plan.passes * OS_RADIX; q += OS_HIST_BLOCK) {
         const uint32_t v = (&s_h[0][0])[q];
