@@ -20,6 +20,9 @@
 #ifndef C3DGS_BWD_CH
 #define C3DGS_BWD_CH 128
 #endif
+#ifndef C3DGS_BWD_LONG_RUN
+#define C3DGS_BWD_LONG_RUN 16   // sum_partials: a lane's run of more than this many staged entries of a chunk is summed by the whole wave
+#endif
 #ifndef C3DGS_BWD_FG
 #define C3DGS_BWD_FG 8
 #endif
@@ -125,7 +128,9 @@ __device__ __forceinline__ uint32_t nth_set_bit(unsigned long long m, uint32_t r
 }
 
 // ---- kernel 1: per-Gaussian sums of the per-tile partials, zero rows, compact list of the blended Gaussians
-__global__ void __launch_bounds__(64 * C3DGS_SUM_WAVES) sum_partials_kernel(const BwdArgs a)
+// 64 registers at most: two 1024-thread workgroups per CU (75 KB of LDS each) are eight waves per SIMD; at 72 registers only one
+// workgroup fits and the kernel runs 8 % slower on synth-v1
+__global__ void __launch_bounds__(64 * C3DGS_SUM_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) sum_partials_kernel(const BwdArgs a)
 {
     constexpr int SW = C3DGS_SUM_WAVES, LIST = 64 * SW;
     const int i = blockIdx.x * LIST + threadIdx.x;
@@ -222,10 +227,37 @@ __global__ void __launch_bounds__(64 * C3DGS_SUM_WAVES) sum_partials_kernel(cons
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t c_hi = min(chi, p0 + CH);
-                for (uint32_t c = max(clo, p0); c < c_hi; c++) {
+                const uint32_t c_lo = max(clo, p0), c_hi = min(chi, p0 + CH);      // this lane's entries of the chunk
+                const bool long_run = c_hi > c_lo + (uint32_t)C3DGS_BWD_LONG_RUN;
+                // A Gaussian that covers hundreds of tiles owns most of a chunk: alone, its lane would add the entries up one
+                // after the other while 63 lanes wait (on a heavy-tailed scene -- a per mille of the splats hundreds of pixels
+                // wide -- nearly every workgroup holds one, and this kernel took 0.73 ms against 0.12 on synth-v1). Long runs
+                // are summed by the whole wave instead: lane l takes entries l, l + 64, ... of the run, then a fixed butterfly;
+                // which path a run takes depends only on its length, so the sums stay reproducible run to run.
+                unsigned long long longm = __ballot(long_run);
+                while (longm) {
+                    const int owner = __ffsll((long long)longm) - 1;
+                    longm &= longm - 1ull;
+                    const uint32_t o_lo = (uint32_t)__shfl((int)c_lo, owner) - p0, o_hi = (uint32_t)__shfl((int)c_hi, owner) - p0;
+                    float part[PARTIAL_FLOATS];
 #pragma unroll
-                    for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] += s_stage(wv, c - p0, q);
+                    for (int q = 0; q < PARTIAL_FLOATS; q++) part[q] = 0.f;
+                    for (uint32_t e = o_lo + (uint32_t)lane_; e < o_hi; e += 64u) {
+#pragma unroll
+                        for (int q = 0; q < PARTIAL_FLOATS; q++) part[q] += s_stage(wv, e, q);
+                    }
+#pragma unroll
+                    for (int q = 0; q < PARTIAL_FLOATS; q++) {
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) part[q] += __shfl_xor(part[q], o);
+                        if (lane_ == owner) acc[q] += part[q];
+                    }
+                }
+                if (!long_run) {
+                    for (uint32_t c = c_lo; c < c_hi; c++) {
+#pragma unroll
+                        for (int q = 0; q < PARTIAL_FLOATS; q++) acc[q] += s_stage(wv, c - p0, q);
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
