@@ -110,6 +110,7 @@ PROTOTYPES = {
     "c3dgs_extract_rot_scale": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "c3dgs_l1_ssim_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "c3dgs_l1_ssim_value": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "c3dgs_l1_ssim_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "c3dgs_qat_workspace_bytes": (C.c_size_t, []),

@@ -700,6 +700,14 @@ int c3dgs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img, con
     return C3DGS_OK;
 }
 
+int c3dgs_l1_ssim_value(const double* sums, double l1_scale, double ssim_scale, double constant, float* out, void* stream)
+{
+    if (!sums || !out) return fail(C3DGS_E_INVALID, "l1_ssim_value: bad arguments");
+    launch_l1_ssim_value(sums, l1_scale, ssim_scale, constant, out, (hipStream_t)stream);
+    C3DGS_STAGE("l1_ssim_value", 0, (hipStream_t)stream);
+    return C3DGS_OK;
+}
+
 int c3dgs_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, const float* dmaps,
                            const float* grad_loss, float l1_coeff, float ssim_coeff, float* dL_dimg, void* stream)
 {

@@ -229,6 +229,7 @@ void launch_extract_rot_scale(int n, const float* cov6, float* rot, float* scale
 void launch_adam(int n_tensors, const c3dgs_adam_tensor* tensors, double beta1, double beta2, double eps, hipStream_t s);
 void launch_abs_accumulate(int64_t n, const float* g, float* acc, hipStream_t s);
 // loss.hip
+void launch_l1_ssim_value(const double* sums, double l1_scale, double ssim_scale, double constant, float* out, hipStream_t s);
 void launch_l1_ssim_forward(int C, int H, int W, const float* img, const float* gt, float* Dmu, float* Ds1, float* Ds12,
                             double* sums, hipStream_t s);
 void launch_l1_ssim_backward(int C, int H, int W, const float* img, const float* gt, const float* Dmu, const float* Ds1,

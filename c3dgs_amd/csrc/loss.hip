@@ -192,6 +192,22 @@ l1_ssim_backward_kernel(int H, int W, const float* __restrict__ img, const float
     }
 }
 
+// value = l1_scale * sum(sums[0..63]) + ssim_scale * sum(sums[64..127]) + constant, in float64, stored as float32: the six torch
+// kernels (a reduction, two scalings, two additions, a cast) that used to follow the forward, in one 64-thread launch
+__global__ void __launch_bounds__(64) l1_ssim_value_kernel(const double* __restrict__ sums, double l1_scale, double ssim_scale,
+                                                           double constant, float* __restrict__ out)
+{
+    double a = sums[threadIdx.x], b = sums[64 + threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (threadIdx.x == 0) out[0] = (float)(l1_scale * a + ssim_scale * b + constant);
+}
+
+void launch_l1_ssim_value(const double* sums, double l1_scale, double ssim_scale, double constant, float* out, hipStream_t s)
+{
+    l1_ssim_value_kernel<<<1, 64, 0, s>>>(sums, l1_scale, ssim_scale, constant, out);
+}
+
 void launch_l1_ssim_forward(int C, int H, int W, const float* img, const float* gt, float* Dmu, float* Ds1, float* Ds12,
                             double* sums, hipStream_t s)
 {

@@ -38,13 +38,14 @@ class _L1SSIM(torch.autograd.Function):
         with torch.cuda.device(x.device):
             rc = L.c3dgs_l1_ssim_forward(Cc, H, W, x.data_ptr(), y.data_ptr(), dmaps.data_ptr() if need_bwd else None,
                                          sums.data_ptr(), _stream(x.device))
-        _lib.check(rc)
-        n = float(Cc * H * W)
-        tot = sums.view(2, 64).sum(1)
-        value = (l1_coeff / n) * tot[0] + (ssim_coeff / n) * tot[1] + const
+            _lib.check(rc)
+            n = float(Cc * H * W)
+            value = torch.empty((), dtype=torch.float32, device=x.device)
+            _lib.check(L.c3dgs_l1_ssim_value(sums.data_ptr(), l1_coeff / n, ssim_coeff / n, float(const), value.data_ptr(),
+                                             _stream(x.device)))
         ctx.coeffs = (float(l1_coeff), float(ssim_coeff))
         ctx.save_for_backward(x, y, dmaps if need_bwd else torch.empty(0))
-        return value.to(torch.float32)
+        return value
 
     @staticmethod
     def backward(ctx, grad_out):

@@ -231,6 +231,11 @@ int c3dgs_draws_upload(int64_t n, int64_t range, const uint32_t* raw_host, uint3
  * writes dL_dimg = grad_loss[0] * dL/dimg  ([C,H,W], fully written). */
 int c3dgs_l1_ssim_forward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, float* dmaps,
                           double* sums /*[128]*/, void* stream);
+/* out[0] (float32, device) = l1_scale * sum(sums[0..63]) + ssim_scale * sum(sums[64..127]) + constant, evaluated in float64:
+ * the scalar the reference assembles with torch arithmetic (finetune.py:48; l1_scale = (1 - lambda) / N, ssim_scale = -lambda / N,
+ * constant = lambda), in one launch */
+int c3dgs_l1_ssim_value(const double* sums /*[128], from c3dgs_l1_ssim_forward*/, double l1_scale, double ssim_scale,
+                        double constant, float* out /*device [1]*/, void* stream);
 int c3dgs_l1_ssim_backward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, const float* dmaps,
                            const float* grad_loss /*device [1]*/, float l1_coeff, float ssim_coeff, float* dL_dimg,
                            void* stream);
