@@ -110,6 +110,14 @@ def test_argument_checks_and_no_cpu_path():
     idx = c3dgs_amd.GaussianRasterizerIndexed(rs, optimize_camera=True)
     with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
         idx(m, m, sc["opacities"], torch.zeros(10, dtype=torch.long), torch.zeros(10, dtype=torch.long))
+    # markVisible: the one-launch pose path is for GPU tensors only; CPU positions take the general path, which refuses them
+    from c3dgs_amd import rasterizer as rz
+    assert rz._mark_visible_from_pose(m, ev) is None
+    assert rz._mark_visible_from_pose(m, torch.eye(4)) is None
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        rast.markVisible(m, extrinsic_vector=ev)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        idx.markVisible(m, extrinsic_vector=ev)
 
 
 def test_join_features_and_settings():
