@@ -731,21 +731,25 @@ wd_fixup_kernel(int64_t N, int C, const float* __restrict__ coefs, const int64_t
 // (786 KB from L2 for K = 4096 x 48), so a workgroup loads every codeword row once into registers and runs the k-ordered
 // FMA chain against WD_FB points whose rows sit in LDS (broadcast reads). Same result as wd_fixup_kernel (which still runs
 // afterwards and picks up whatever did not fit the list).
-constexpr int WD_FB = 4;
+// WD_FT threads per workgroup: a thread's share of the codebook is a serial chain of row loads (786 KB per group from L2, latency
+// bound -- 16 rows per thread with 256 threads took 23-28 us whatever the list's length, a quarter of a rank's 2^15-point Lloyd
+// step); 512 threads walk 8 rows each (1024 threads leave 128 registers each: the row prefetch spills).
+constexpr int WD_FB = 4, WD_FT = 512;
 template <int K>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(WD_FT)
 wd_fixup_list_kernel(int C, const float* __restrict__ coefs, const int64_t* __restrict__ gather, const float* __restrict__ codebook,
                      float* __restrict__ out_dist, int64_t* __restrict__ out_idx, const int* __restrict__ flag_list, int flag_cap)
 {
+    constexpr int NW = WD_FT / 64;
     __shared__ float s_x[WD_FB][K];
-    __shared__ float s_best[WD_FB][4];
-    __shared__ int s_besti[WD_FB][4];
+    __shared__ float s_best[WD_FB][NW];
+    __shared__ int s_besti[WD_FB][NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int count = min(flag_list[0], flag_cap);
     for (int base = (int)blockIdx.x * WD_FB; base < count; base += (int)gridDim.x * WD_FB) {
         const int np = min(WD_FB, count - base);
         __syncthreads();                                             // previous group's LDS has been read
-        for (int q = tid; q < WD_FB * K; q += 256) {
+        for (int q = tid; q < WD_FB * K; q += WD_FT) {
             const int p = q / K, k = q - p * K;
             float v = 0.f;
             if (p < np) {
@@ -759,7 +763,7 @@ wd_fixup_list_kernel(int C, const float* __restrict__ coefs, const int64_t* __re
         int besti[WD_FB];
 #pragma unroll
         for (int p = 0; p < WD_FB; p++) { best[p] = FLT_MAX; besti[p] = 0x7fffffff; }
-        for (int c = tid; c < C; c += 256) {
+        for (int c = tid; c < C; c += WD_FT) {
             float cb[K];
             const float* src = codebook + (size_t)c * K;
 #pragma unroll
@@ -792,7 +796,7 @@ wd_fixup_list_kernel(int C, const float* __restrict__ coefs, const int64_t* __re
             float b = s_best[tid][0];
             int bi = s_besti[tid][0];
 #pragma unroll
-            for (int w = 1; w < 4; w++)
+            for (int w = 1; w < NW; w++)
                 if (s_best[tid][w] < b || (s_best[tid][w] == b && s_besti[tid][w] < bi)) { b = s_best[tid][w]; bi = s_besti[tid][w]; }
             const int64_t n = flag_list[1 + base + tid];
             out_dist[n] = b;
@@ -866,7 +870,7 @@ static void launch_wd_mfma(int64_t N, int C, const float* coefs, const int64_t* 
     else wd_mfma_kernel<K, false><<<g1, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
     if (listed) {
         const unsigned gl = (unsigned)std::min<int64_t>(1024, ((int64_t)flag_cap + WD_FB - 1) / WD_FB);
-        wd_fixup_list_kernel<K><<<gl, 256, 0, s>>>(C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
+        wd_fixup_list_kernel<K><<<gl, WD_FT, 0, s>>>(C, coefs, gather, codebook, out_dist, out_idx, flag_list, flag_cap);
     }
     // whatever is still flagged: only possible when the list could not hold every point
     if (!listed || (int64_t)flag_cap < N) wd_fixup_kernel<K><<<g2, 256, 0, s>>>(N, C, coefs, gather, codebook, out_dist, out_idx);
