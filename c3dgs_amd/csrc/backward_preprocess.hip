@@ -21,7 +21,8 @@
 #define C3DGS_BWD_CH 128
 #endif
 #ifndef C3DGS_BWD_LONG_RUN
-#define C3DGS_BWD_LONG_RUN 16   // sum_partials: a lane's run of more than this many staged entries of a chunk is summed by the whole wave
+#define C3DGS_BWD_LONG_RUN 32   // sum_partials: a lane's run of more than this many staged entries of a chunk is summed by the whole wave
+                                // (tools/ablate_bwdpre.sh, stage ms synth-v1 / heavy tail: 8 -> 0.316 / 0.280, 16 -> 0.261 / 0.279, 32 -> 0.256 / 0.276)
 #endif
 #ifndef C3DGS_BWD_FG
 #define C3DGS_BWD_FG 8
