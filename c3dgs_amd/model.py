@@ -680,10 +680,11 @@ class GaussianModel:
         (means3D, means2D, opac, sfac, scales_n, rotations, shs, sh_idx, g_idx) = _QatGetters.apply(
             self, (visible, rank, read), self._feature_indices, self._gaussian_indices, self._xyz, screenspace_points,
             self._opacity, self._scaling_factor, self._scaling, self._rotation, self._features_dc, self._features_rest)
-        rasterizer = GaussianRasterizerIndexed(raster_settings=settings, optimize_camera=True)
-        image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, sh_indices=sh_idx, g_indices=g_idx,
-                                  colors_precomp=None, opacities=opac, scales=scales_n, scale_factors=sfac,
-                                  rotations=rotations, cov3D_precomp=None, extrinsic_vector=settings.extrinsic_vector)
+        # what GaussianRasterizerIndexed(settings, optimize_camera=True)(...) calls, without building an nn.Module per view
+        # (the host has ~0.2 ms of Python between the visible count's arrival and the rasterizer's first launch, and the GPU
+        # idles for the part of it the getter kernels do not cover)
+        image, radii = _rz.rasterize_gaussians_indexed_camera(means3D, means2D, shs, sh_idx, g_idx, _rz._empty(), opac, scales_n, sfac,
+                                                              rotations, _rz._empty(), settings, settings.extrinsic_vector)
         return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
                 "visible": visible.bool()}
 
