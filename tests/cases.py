@@ -39,6 +39,10 @@ def make_case(name, P=4000, W=200, H=136, focal=125.0, seed=7, scale_median=0.03
         P = 257
     if name == "p8193":          # one key past an 8192-item tile of the sorts
         P = 8193
+    if name == "p12289":         # one key past a 12288-item tile of the depth sort (keys + ids + packed rectangles: two tiles)
+        P = 12289
+    if name == "p24577":         # three depth-sort tiles, the last holding one item
+        P = 24577
     ev = (0.05, -0.03, 0.02, 0.99, 0.1, -0.05, 0.2)
     if name == "equal_depth":    # identity camera + one z: all depth keys tie -> the stable sort must keep id order
         ev = (0, 0, 0, 1, 0, 0, 0)
@@ -114,4 +118,4 @@ def oracle_forward(inp, cam):
 FORWARD_CASES = ["tiny", "base", "odd_size", "behind", "all_behind", "empty", "deg0", "deg1", "deg2", "no_clamp",
                  "clamp_hits", "black_bg", "scale_mod", "colors_precomp", "cov_precomp", "frustum_edge", "indexed",
                  "indexed_deg1", "indexed_scale_mod", "wide_depth", "deep_tile", "huge_splats", "one_tile", "p257", "p8193",
-                 "equal_depth"]
+                 "p12289", "p24577", "equal_depth"]
