@@ -77,6 +77,23 @@ def test_rocprim_fallback_gives_the_same_sorted_lists():
     assert " passed" in r.stdout
 
 
+def test_depth_sort_gather_path_gives_the_same_sorted_lists():
+    """By default the depth sort carries every Gaussian's tile rectangle through its passes as a packed second payload (grids up
+    to 255 x 255 tiles); C3DGS_DEPTH_SORT_GATHER=1 makes it gather the rectangles behind the last pass instead (what larger
+    grids get). The parity cases that compare keys / point lists / ranges bit-exactly must pass on that path too. Child process:
+    the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, C3DGS_DEPTH_SORT_GATHER="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_raster_gpu.py", "-q", "-m", "gpu", "-x",
+                        "-k", "forward_parity and (base or wide_depth or p8193 or p12289 or equal_depth or indexed or huge_splats)"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 _TIMEOUT_CHILD = r"""
 import numpy as np, torch, sys
 from tests import cases, gpu_util, synth
